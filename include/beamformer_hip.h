@@ -1,0 +1,164 @@
+/*
+ * beamformer_hip.h -- C-ABI of libbeamformer_hip.so, the MI355X (gfx950) drop-in for the reference's
+ * CPU delay-and-sum path.
+ *
+ * PART 1 re-exports, with identical names, argument order and ownership rules, the plain-C symbols the
+ * reference links into its Cython extensions (`beamformer` via PC/setup.py:22-23, `tests` via
+ * PC/src/benchmark.pyx:28-55).  Each prototype cites the reference declaration it replaces.
+ *
+ * Differences a maintainer must know:
+ *   - Sizes.  The reference bakes N_SAMPLES / MAX_RES_X / MAX_RES_Y / N_TAPS / N_MICROPHONES into config.h
+ *     at build time.  Here they are run-time state: defaults are the as-shipped PC/src/config.json, replaced
+ *     by bf_configure(...) or, on first use, by the JSON file named in $BF_CONFIG.
+ *   - Errors.  Reference functions return void and never check anything.  These keep the void signatures;
+ *     a failure (no GPU, bad size, HIP error) is printed to stderr, recorded for bf_last_error() and the
+ *     output buffer is filled with NaN so it cannot pass for a result.  There is NO CPU fallback.
+ *   - Process model.  The HIP context is created lazily by the first load_* / mimo_* call in the CALLING
+ *     process (the reference forks its workers before loading tables: PC/src/main.pyx:172-181,707).
+ *   - Tables are copied to the GPU by load_*; the caller's buffer may be freed afterwards (as in the
+ *     reference, which malloc+memcpy's: PC/src/algorithms/pad_and_sum.c:147-151).
+ *
+ * PART 2 (bf_* names) is the extension surface: run-time configuration, device-resident / batched entry
+ * points that take HIP device pointers and a stream (what bench.py and the multi-GPU path use), the steering
+ * table generators of PC/src/directions.pyx, and error reporting.
+ */
+#ifndef BEAMFORMER_HIP_H
+#define BEAMFORMER_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ===================================================================== PART 1: reference symbols */
+
+/* ---- PC/src/algorithms/pad_and_sum.h:5-13 ---- */
+void pad_delay(float *signal, float *out, int pos_pad);                                   /* :5  */
+void miso_pad(float *signals, float *out, int *adaptive_array, int n, int offset);        /* :6  */
+void miso_pad2(float *signals, float *out, int *adaptive_array, int n, int offset);       /* :7  */
+void mimo_pad(float *signals, float *image, int *adaptive_array, int n);                  /* :8  */
+void load_coefficients_pad(int *whole_samples, int n);                                    /* :10 */
+void load_coefficients_pad2(int *whole_miso, int n);                                      /* :11 */
+void unload_coefficients_pad(void);                                                       /* :12 */
+void unload_coefficients_pad2(void);                                                      /* :13 */
+
+/* ---- PC/src/algorithms/lerp_and_sum.h:4-12 ---- */
+void lerp_delay(float *signal, float *out, float h, int pad);                             /* :4  */
+void miso_lerp(float *signals, float *out, int *adaptive_array, int n, int offset);       /* :6  */
+void mimo_lerp(float *signals, float *image, int *adaptive_array, int n);                 /* :8  */
+void load_coefficients_lerp(float *delays, int n);                                        /* :10 */
+void unload_coefficients_lerp(void);                                                      /* :12 */
+
+/* ---- PC/src/algorithms/convolve_and_sum.h:4-22 (convolve_naive, :12, is declared but never defined there) ---- */
+void convolve_delay_naive_add(float *signal, float *h, float *out);                       /* :4  */
+void convolve_delay_vectorized(float *signal, float *h, float *out);                      /* :6  */
+void convolve_delay_vectorized_add(float *signal, float *h, float *out);                  /* :8  */
+void convolve_delay_naive(float *signal, float *out, float *h);                           /* :10 */
+void mimo_convolve_naive(float *signals, float *image, int *adaptive_array, int n);       /* :14 */
+void miso_convolve_vectorized(float *signals, float *out, int *adaptive_array, int n, int offset); /* :16 */
+void mimo_convolve_vectorized(float *signals, float *image, int *adaptive_array, int n);  /* :18 */
+void load_coefficients_convolve(float *h, int n);                                         /* :20 */
+void unload_coefficients_convolve(void);                                                  /* :22 */
+
+/* ---- PC/src/algorithms/hybrid_convolve_and_sum.h:4-12 ---- */
+void convolve_hybrid_delay_add(float *signal, float *h, int pad, float *out);             /* :4  */
+void miso_convolve_hybrid(float *signals, float *out, int *adaptive_array, int n, int offset); /* :6 */
+void mimo_convolve_hybrid(float *signals, float *image, int *adaptive_array, int n);      /* :8  */
+void load_coefficients_convolve_hybrid(float *h, int n);                                  /* :10 */
+void unload_coefficients_convolve_hybrid(void);                                           /* :12 */
+
+/* ---- PC/src/api.h:8-21, the shims that pair get_data() with an algorithm (PC/src/api.c:951-1104).
+ * The UDP receiver / SysV ring buffer behind get_data() is out of scope; here get_data() copies the frame
+ * most recently published with bf_publish_frame() (the hook a receiver process calls once per window). ---- */
+void get_data(float *signals);                                                            /* api.h:7  */
+void pad_mimo(float *image, int *adaptive_array, int n);                                  /* api.h:10 */
+void lerp_mimo(float *image, int *adaptive_array, int n);                                 /* api.h:11 */
+void convolve_mimo_naive(float *image, int *adaptive_array, int n);                       /* api.h:12 */
+void convolve_mimo_vectorized(float *image, int *adaptive_array, int n);                  /* api.h:13 */
+void mimo_truncated(float *image, int *adaptive_array, int n);                            /* api.h:16 */
+void load_coefficients2(int *whole_samples, int n);                                       /* api.h:17 */
+void miso_steer_listen(float *out, int *adaptive_array, int n, int steer_offset);         /* api.h:19 */
+
+/* ===================================================================== PART 2: extensions */
+
+enum bf_algo {
+    BF_PAD = 0,        /* mimo_pad                  */
+    BF_LERP = 1,       /* mimo_lerp                 */
+    BF_HYBRID = 2,     /* mimo_convolve_hybrid      */
+    BF_FIR_NAIVE = 3,  /* mimo_convolve_naive       */
+    BF_FIR_VEC = 4     /* mimo_convolve_vectorized  */
+};
+
+/* Run-time replacement of the config.h size macros (PC/src/config.json:3-11).  Returns 0, or -1 (see
+ * bf_last_error).  Changing sizes drops every loaded table. */
+int bf_configure(int n_microphones, int n_samples, int max_res_x, int max_res_y, int n_taps);
+/* Same, reading the keys N_MICROPHONES, N_SAMPLES, MAX_RES_X, MAX_RES_Y, N_TAPS of section "general" from a
+ * file laid out like PC/src/config.json. */
+int bf_configure_from_json(const char *path);
+/* Current sizes: out[0..4] = N_MICROPHONES, N_SAMPLES, MAX_RES_X, MAX_RES_Y, N_TAPS. */
+void bf_get_config(int out[5]);
+
+/* Last failure of any entry point on this thread's process ("" when none); bf_clear_error resets it. */
+const char *bf_last_error(void);
+void bf_clear_error(void);
+
+/* 1 when a gfx9xx GPU is usable by this process, else 0 (never initialises a context as a side effect of
+ * loading the library). */
+int bf_gpu_available(void);
+/* Select the HIP device (default 0, or $BF_DEVICE) before the first load_* call. */
+int bf_set_device(int device);
+
+/* Frame hand-off for the api.h shims: copies n_microphones*n_samples floats (mic-major). */
+void bf_publish_frame(const float *signals);
+
+/* ---- device-resident, batched delay-and-sum (the throughput path) ----
+ * d_signals : HIP device pointer, float32 [frames][m_total][N_SAMPLES], mic-major
+ * d_images  : HIP device pointer, float32 [frames][image_stride]; direction d of the launched range is
+ *             written to d_images[f*image_stride + d - dir_begin]
+ * adaptive_array / n : HOST array of the active mic rows, as in the reference calls
+ * [dir_begin, dir_end) : shard of the flat direction grid 0..MAX_RES_X*MAX_RES_Y handled by this call
+ * stream    : hipStream_t (0 = null stream).  Enqueue only: no host synchronisation, graph-capturable once
+ *             the adaptive array has been uploaded by a first call.
+ * Returns 0 or -1. */
+int bf_das_device(int algo, const float *d_signals, int m_total, float *d_images, int image_stride, int frames,
+                  const int *adaptive_array, int n, int dir_begin, int dir_end, void *stream);
+
+/* Launch geometry the planner picks for a call like the above (no GPU needed): out[0..9] = nc, lead,
+ * row_stride, mic_chunk, n_chunks, waves, dpw, tile_dirs, n_tiles, lds_bytes.  Returns 0 or -1. */
+int bf_plan_das(int algo, int n, int frames, int dir_begin, int dir_end, int max_whole, int n_cus, long long out[10]);
+
+/* Copies of the tables as resident on the GPU after load_coefficients_lerp / _convolve_hybrid (the reference
+ * keeps them in file-scope globals: lerp_and_sum.c:33-34, hybrid_convolve_and_sum.c:40-41). */
+int bf_get_lerp_tables(int *whole, float *h, int n);
+int bf_get_hybrid_tables(int *whole, float *taps, int n);
+
+/* ---- steering tables: PC/src/directions.pyx, bit-exact, host C++ (float64 with the float32-typed
+ * constants of config.pxd:14-23) ---- */
+typedef struct bf_geometry {
+    int rows, columns;          /* ROWS, COLUMNS                    config.json:7-8   */
+    int arrays;                 /* _ACTIVE_MICS (8x8 tiles)         directions.pyx:16 */
+    int skip_n_mics;            /* SKIP_N_MICS                      config.json:20    */
+    float sample_rate;          /* SAMPLE_RATE                      config.json:16    */
+    float propagation_speed;    /* PROPAGATION_SPEED                config.json:21    */
+    float element_distance;     /* ELEMENT_DISTANCE                 config.json:17    */
+    float view_angle;           /* VIEW_ANGLE                       config.json:13    */
+    float z;                    /* Z                                config.json:11    */
+} bf_geometry;
+void bf_default_geometry(bf_geometry *g);                                   /* as-shipped config.json values */
+/* directions.pyx:35-87; `unused`/`n_unused` = contents of unused_mics.npy (already offset), may be NULL/0.
+ * Writes up to rows*columns*arrays sorted indices, returns how many. */
+int bf_active_microphones(const bf_geometry *g, const int *unused, int n_unused, int *active_out);
+/* directions.pyx:17-32; r_prime_out = float64 [2][n_active]. Returns n_active. */
+int bf_calc_r_prime(const bf_geometry *g, const int *unused, int n_unused, double *r_prime_out);
+/* directions.pyx:90-124; delays_out = float64 [max_res_x][max_res_y][n_active]. Returns n_active or -1. */
+int bf_calculate_delays(const bf_geometry *g, int max_res_x, int max_res_y, const int *unused, int n_unused, double *delays_out);
+/* directions.pyx:189-205 / :207-226; taps_out = float64[8] / float32[n_taps]. */
+void bf_get_h(double frac, double *taps_out);
+void bf_get_h2(double delay, int n_taps, float *taps_out);
+/* The Python loops over those two (directions.pyx:240-243, :272-275) as one call: float32 [n][8] / [n][n_taps]. */
+void bf_get_h_batch(const double *frac, long long n, float *taps_out);
+void bf_get_h2_batch(const double *delay, long long n, int n_taps, float *taps_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEAMFORMER_HIP_H */

@@ -253,7 +253,39 @@ void oracle_mimo_convolve_hybrid(const float *signals, float *image, const int *
     free(out);
 }
 
-/* ---------------------------------------------------------------- helpers for the bench's cpu_baseline leg */
+/* ---------------------------------------------------------------- helpers for tests / the bench's cpu_baseline leg */
+
+/* mean power of a raw steered block (exposes block_power; `out` is overwritten with out/n as in the reference) */
+float oracle_block_power(float *out, int n_mics) { return block_power(out, n_mics); }
+
+/* images of the flat directions [d0, d1) only: image[d - d0].  algo: 0 pad, 1 lerp, 2 hybrid, 3 fir naive, 4 fir vectorized.
+ * Same code path as the full mimo_* loops; lets tests sample directions of sizes whose full image takes minutes on a CPU. */
+void oracle_mimo_range(int algo, const float *signals, float *image, const int *mics, int n, int d0, int d1)
+{
+    float *out = (float *)malloc((size_t)g_nsamp * sizeof(float));
+    for (int d = d0; d < d1; d++) {
+        switch (algo) {
+        case 0: oracle_miso_pad(signals, out, mics, n, d * n); break;
+        case 1: oracle_miso_lerp(signals, out, mics, n, d * n); break;
+        case 2:
+            memset(out, 0, (size_t)g_nsamp * sizeof(float));
+            for (int m = 0; m < n; m++)
+                oracle_convolve_hybrid_delay_add(signals + (size_t)mics[m] * g_nsamp, g_hyb_taps + ((size_t)d * n + m) * g_taps,
+                                                 g_hyb_whole[(size_t)d * n + m], out);
+            break;
+        default:
+            memset(out, 0, (size_t)g_nsamp * sizeof(float));
+            for (int m = 0; m < n; m++) {
+                const float *sig = signals + (size_t)mics[m] * g_nsamp;
+                const float *h = g_fir_taps + ((size_t)d * n + m) * g_taps;
+                if (algo == 4) oracle_convolve_delay_vectorized_add(sig, h, out);
+                else           oracle_convolve_delay_naive(sig, out, h);
+            }
+        }
+        image[d - d0] = block_power(out, n);
+    }
+    free(out);
+}
 
 void oracle_unload_all(void)
 {

@@ -105,6 +105,23 @@ class Oracle(_Base):
         self.lib.oracle_configure(self.N, self.X, self.Y, self.T)   # the .so is shared between instances
         return getattr(self.lib, self.pre + name)
 
+    def load(self, algo, table):
+        """Load the coefficient table of `algo` (0 pad: int32 whole; 1 lerp / 2 hybrid: float32 delays; 3/4 fir: taps)."""
+        if algo == 0:
+            t = np.ascontiguousarray(table, dtype=np.int32).ravel()
+            self._fn("load_coefficients_pad")(_i(t), C.c_int(t.size))
+        else:
+            t = np.ascontiguousarray(table, dtype=np.float32).ravel()
+            name = {1: "load_coefficients_lerp", 2: "load_coefficients_convolve_hybrid"}.get(algo, "load_coefficients_convolve")
+            self._fn(name)(_f(t), C.c_int(t.size))
+
+    def mimo_range(self, algo, signals, mics, d0, d1):
+        """Images of flat directions [d0, d1) with the table loaded by `load` (float32 [d1-d0])."""
+        s, m = _prep(signals, mics)
+        img = np.zeros(d1 - d0, dtype=np.float32)
+        self._fn("mimo_range")(C.c_int(algo), _f(s), _f(img), _i(m), C.c_int(m.size), C.c_int(d0), C.c_int(d1))
+        return img
+
     def lerp_tables(self, delays_f32):
         d = np.ascontiguousarray(delays_f32, dtype=np.float32).ravel()
         self._fn("load_coefficients_lerp")(_f(d), C.c_int(d.size))

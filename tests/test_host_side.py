@@ -1,0 +1,111 @@
+"""CPU: the product's host side through the C-ABI -- steering tables (csrc/directions.cpp) bit-exact against the
+golden vectors, exported symbols, launch planning, and loud failure when no GPU is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import util
+from util import CONFIGS, golden, sha
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_product_tables_bit_exact(native, name):
+    from lib import directions
+    c, g = util.configure(name), golden(name)
+    act, n = directions.active_microphones()
+    assert n == c["M"] and np.array_equal(act, g["active_mics"])
+    assert directions.calc_r_prime(float(np.float32(0.02))).tobytes() == g["r_prime"].tobytes()
+    d = directions.calculate_delays()
+    assert d.shape == (c["X"], c["Y"], c["M"]) and d.dtype == np.float64
+    assert sha(d) == str(g["delay_sha256"])
+    assert sha(d.astype(int).astype(np.int32)) == str(g["whole_sha256"])
+    assert sha(np.float32(d)) == str(g["delay_f32_sha256"])
+
+
+def test_product_taps_bit_exact(native):
+    from lib import directions
+    util.configure("cfg1")
+    g = golden("cfg1")
+    for x, h1, h2 in zip(g["tap_probe_delay"], g["tap_probe_get_h"], g["tap_probe_get_h2"]):
+        assert np.array_equal(directions.get_h(float(x)), h1)
+        assert np.array_equal(directions.get_h2(float(x), N=8), h2)
+    whole, h = directions.calculate_coefficients()
+    assert np.array_equal(whole, g["delay"].astype(int)) and np.array_equal(h, g["taps_get_h"])
+    assert np.array_equal(directions.compute_convolve_h(), g["taps_get_h2"])
+
+
+def test_product_tables_match_oracle_on_other_geometry(native):
+    """A geometry no fixture covers (2 tiles, every 2nd mic, other pitch/angle/distance): product C++ == NumPy oracle."""
+    import directions_np as D
+    from interface import config
+    from lib import directions
+    config.configure(N_MICROPHONES=128, ACTIVE_TILES=2, SKIP_N_MICS=2, MAX_RES_X=23, MAX_RES_Y=17, ELEMENT_DISTANCE=0.025,
+                     VIEW_ANGLE=59.0, Z=1.5, SAMPLE_RATE=44100.0, PROPAGATION_SPEED=343.0)
+    try:
+        want = D.calculate_delays(23, 17, arrays=2, fs=44100.0, c=343.0, d=0.025, view_angle=59.0, z=1.5, skip=2)
+        got = directions.calculate_delays()
+        assert got.shape == want.shape and got.tobytes() == want.tobytes()
+        assert np.array_equal(directions.active_microphones()[0], D.active_microphones(arrays=2, skip=2)[0])
+    finally:
+        config.configure(SKIP_N_MICS=1, ELEMENT_DISTANCE=0.02, Z=1.0, SAMPLE_RATE=48828.0, PROPAGATION_SPEED=340.0)
+
+
+def test_every_declared_symbol_is_exported(native):
+    text = open(os.path.join(util.ROOT, "include", "beamformer_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", text)
+    assert len(names) > 50
+    missing = [n for n in names if not hasattr(native.lib, n)]
+    assert not missing, missing
+
+
+def test_plan_geometry(native):
+    """LDS sizing / tiling chosen on the host for the BASELINE sizes (no GPU needed)."""
+    out = (C.c_longlong * 10)()
+    util.configure("cfg2")
+    assert native.lib.bf_plan_das(native.LERP, 64, 190, 0, 101 * 101, 12, 256, out) == 0
+    nc, lead, rs, mc, nch, waves, dpw, tile, ntiles, lds = list(out)
+    assert nc == 4 and mc == 64 and nch == 1 and dpw == 1 and lds <= 80 * 1024 and ntiles % 8 == 0 and lead >= 13
+    util.configure("cfg5")
+    assert native.lib.bf_plan_das(native.LERP, 256, 1, 0, 361 * 361, 47, 256, out) == 0
+    nc, lead, rs, mc, nch, waves, dpw, tile, ntiles, lds = list(out)
+    assert nc == 16 and nch * mc >= 256 and nch > 1 and dpw == 4 and lds <= 160 * 1024
+    # unsupported shapes are refused with a message, not launched
+    assert native.lib.bf_plan_das(native.FIR_VEC, 64, 1, 0, 1, 0, 256, out) == 0
+    assert native.lib.bf_configure(64, 4096, 11, 11, 8) == -1
+    with pytest.raises(native.BeamformerError):
+        native.check()
+    util.configure("cfg1")
+
+
+def test_config_json_roundtrip(native, tmp_path):
+    p = tmp_path / "config.json"
+    p.write_text('{"general": {"N_MICROPHONES": 64, "N_SAMPLES": 128, "MAX_RES_X": 9, "MAX_RES_Y": 7, "N_TAPS": 16}}')
+    assert native.lib.bf_configure_from_json(str(p).encode()) == 0
+    out = (C.c_int * 5)()
+    native.lib.bf_get_config(out)
+    assert list(out) == [64, 128, 9, 7, 16]
+    assert native.lib.bf_configure_from_json(b"/nonexistent.json") == -1
+    with pytest.raises(native.BeamformerError):
+        native.check()
+    util.configure("cfg1")
+
+
+def test_fails_loudly_without_gpu(native):
+    """No silent CPU path: without a GPU every compute entry point reports an error and returns NaN."""
+    if native.gpu_available():
+        pytest.skip("a GPU is present")
+    from lib import tests as T
+    import synth
+    util.configure("cfg1")
+    with pytest.raises(native.BeamformerError, match="no usable HIP device"):
+        T.mimo_pad_wrapper(synth.s2_noise(64, 256))
+    img = np.zeros(121, dtype=np.float32)
+    sig = synth.s2_noise(64, 256)
+    mics = np.arange(64, dtype=np.int32)
+    native.lib.mimo_pad(native.fptr(sig), native.fptr(img), native.iptr(mics), 64)
+    assert np.isnan(img).all()
+    native.lib.bf_clear_error()

@@ -1,0 +1,774 @@
+// beamformer_api.cpp -- the C-ABI of include/beamformer_hip.h: process-global state, table upload, launch glue.
+//
+// Mirrors the reference's process model: one table set per process, loaded once before the frame loop
+// (PC/src/main.pyx:172-181), single-threaded callers.  Everything numerical runs in das_kernels.hip; this
+// file only validates, copies and enqueues.  There is no CPU compute path: when no GPU is usable every entry
+// point reports an error and poisons its output with NaN.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/beamformer_hip.h"
+#include "das_kernels.h"
+
+namespace {
+
+using bf::Algo;
+
+struct Sizes {
+    int n_microphones = 256, n_samples = 256, res_x = 57, res_y = 32, n_taps = 8;  // PC/src/config.json:3-11
+    int dirs() const { return res_x * res_y; }
+};
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;  // elements
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+// One loaded coefficient set (what a load_coefficients_* call leaves behind).
+struct TableSet {
+    bool loaded = false;
+    int entries = 0;      // n of the load call = D * M
+    int max_whole = 0;
+    DevBuf<int32_t> whole;
+    DevBuf<float> frac;
+    DevBuf<float> taps;
+    void drop() { loaded = false; entries = 0; max_whole = 0; whole.release(); frac.release(); taps.release(); }
+};
+
+enum Slot { SLOT_PAD = 0, SLOT_LERP, SLOT_FIR, SLOT_HYBRID, SLOT_TRUNC, SLOT_COUNT };
+
+struct State {
+    std::mutex mu;
+    Sizes sz;
+    bool sizes_from_env_done = false;
+    int device = -1;
+    bool device_ready = false;
+    int n_cus = 256;
+    hipStream_t stream = nullptr;
+    TableSet tab[SLOT_COUNT];
+    std::vector<int> pad2_host;          // load_coefficients_pad2: per-mic delays (pad_and_sum.c:153-157)
+    // scratch for the host-pointer entry points
+    DevBuf<float> d_frame, d_image, d_out, d_init, d_one_taps, d_one_frac;
+    DevBuf<int32_t> d_mics, d_one_whole;
+    std::vector<int> mics_host;          // what d_mics currently holds
+    std::vector<float> published;        // bf_publish_frame / get_data
+    std::vector<int> disabled_mics;      // get_data's dead-microphone rows
+    bool disabled_default = true;
+    std::string err;
+};
+
+State& S()
+{
+    static State s;
+    return s;
+}
+
+void set_error(const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    S().err = buf;
+    fprintf(stderr, "[beamformer_hip] error: %s\n", buf);
+}
+
+void poison(float* out, size_t n)
+{
+    if (!out) return;
+    for (size_t i = 0; i < n; ++i) out[i] = std::numeric_limits<float>::quiet_NaN();
+}
+
+#define HIP_OK(expr)                                                                          \
+    ([&]() -> bool {                                                                          \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) { set_error("%s -> %s", #expr, hipGetErrorString(e__)); return false; } \
+        return true;                                                                          \
+    }())
+
+// ---- config.json reader: "KEY": number, anywhere in the file (keys are unique in PC/src/config.json)
+bool json_number(const std::string& text, const char* key, double* out)
+{
+    const std::string pat = std::string("\"") + key + "\"";
+    size_t pos = text.find(pat);
+    if (pos == std::string::npos) return false;
+    pos = text.find(':', pos + pat.size());
+    if (pos == std::string::npos) return false;
+    const char* s = text.c_str() + pos + 1;
+    char* end = nullptr;
+    const double v = strtod(s, &end);
+    if (end == s) return false;
+    *out = v;
+    return true;
+}
+
+bool apply_sizes(int mics, int n, int x, int y, int t)
+{
+    if (mics < 1 || n < 1 || x < 1 || y < 1 || t < 1 || (long long)x * y > (1 << 24)) {
+        set_error("bf_configure: invalid sizes N_MICROPHONES=%d N_SAMPLES=%d MAX_RES_X=%d MAX_RES_Y=%d N_TAPS=%d", mics, n, x, y, t);
+        return false;
+    }
+    if (n > 1024) { set_error("bf_configure: N_SAMPLES=%d > 1024 is not supported by the gfx950 kernels", n); return false; }
+    State& s = S();
+    const Sizes old = s.sz;
+    s.sz.n_microphones = mics; s.sz.n_samples = n; s.sz.res_x = x; s.sz.res_y = y; s.sz.n_taps = t;
+    if (old.n_samples != n || old.res_x != x || old.res_y != y || old.n_taps != t)
+        for (auto& t2 : s.tab) t2.drop();
+    s.published.clear();
+    return true;
+}
+
+bool configure_from_json(const char* path)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) { set_error("cannot open config file %s", path); return false; }
+    std::string text;
+    char buf[4096];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof(buf), f)) > 0) text.append(buf, got);
+    fclose(f);
+    Sizes z = S().sz;
+    double v;
+    if (json_number(text, "N_MICROPHONES", &v)) z.n_microphones = (int)v;
+    if (json_number(text, "N_SAMPLES", &v)) z.n_samples = (int)v;
+    if (json_number(text, "MAX_RES_X", &v)) z.res_x = (int)v;
+    if (json_number(text, "MAX_RES_Y", &v)) z.res_y = (int)v;
+    if (json_number(text, "N_TAPS", &v)) z.n_taps = (int)v;
+    return apply_sizes(z.n_microphones, z.n_samples, z.res_x, z.res_y, z.n_taps);
+}
+
+void sizes_from_env_once()
+{
+    State& s = S();
+    if (s.sizes_from_env_done) return;
+    s.sizes_from_env_done = true;
+    if (const char* p = getenv("BF_CONFIG")) (void)configure_from_json(p);
+}
+
+// Lazy, per-process HIP bring-up (never at library load: callers fork first).
+bool ensure_device()
+{
+    State& s = S();
+    sizes_from_env_once();
+    if (s.device_ready) return true;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count < 1) {
+        set_error("no usable HIP device (%s); this library has no CPU fallback", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return false;
+    }
+    int dev = s.device;
+    if (dev < 0) { const char* p = getenv("BF_DEVICE"); dev = p ? atoi(p) : 0; }
+    if (dev >= count) { set_error("HIP device %d requested but only %d present", dev, count); return false; }
+    if (!HIP_OK(hipSetDevice(dev))) return false;
+    hipDeviceProp_t prop;
+    if (!HIP_OK(hipGetDeviceProperties(&prop, dev))) return false;
+    if (strncmp(prop.gcnArchName, "gfx9", 4) != 0) {
+        set_error("device %d is %s; this build carries gfx950 code only", dev, prop.gcnArchName);
+        return false;
+    }
+    s.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (!HIP_OK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking))) return false;
+    s.device = dev;
+    s.device_ready = true;
+    return true;
+}
+
+template <typename T>
+bool upload(DevBuf<T>& dst, const T* src, size_t n)
+{
+    if (!HIP_OK(dst.reserve(n))) return false;
+    return HIP_OK(hipMemcpy(dst.p, src, n * sizeof(T), hipMemcpyHostToDevice));
+}
+
+bool upload_mics(const int* adaptive, int n, int* max_row)
+{
+    State& s = S();
+    int mx = -1;
+    for (int i = 0; i < n; ++i) {
+        if (adaptive[i] < 0) { set_error("adaptive_array[%d] = %d is negative", i, adaptive[i]); return false; }
+        mx = std::max(mx, adaptive[i]);
+    }
+    *max_row = mx;
+    if ((int)s.mics_host.size() == n && std::equal(adaptive, adaptive + n, s.mics_host.begin()) && s.d_mics.p) return true;
+    if (!upload(s.d_mics, adaptive, (size_t)n)) return false;
+    s.mics_host.assign(adaptive, adaptive + n);
+    return true;
+}
+
+int slot_of(int algo)
+{
+    switch (algo) {
+        case bf::ALGO_PAD: return SLOT_PAD;
+        case bf::ALGO_LERP: return SLOT_LERP;
+        case bf::ALGO_HYBRID: return SLOT_HYBRID;
+        case bf::ALGO_FIR_NAIVE:
+        case bf::ALGO_FIR_VEC: return SLOT_FIR;
+        default: return -1;
+    }
+}
+
+const char* loader_name(int slot)
+{
+    static const char* n[] = {"load_coefficients_pad", "load_coefficients_lerp", "load_coefficients_convolve",
+                              "load_coefficients_convolve_hybrid", "load_coefficients2"};
+    return n[slot];
+}
+
+// Fill the launch descriptor shared by every entry point.  `n` = active mics, table must hold D*n entries.
+bool describe(int algo, int slot, int n, bf::DasLaunch* L)
+{
+    State& s = S();
+    const TableSet& t = s.tab[slot];
+    if (!t.loaded) { set_error("%s has not been called", loader_name(slot)); return false; }
+    const int D = s.sz.dirs();
+    const bool fir = (slot == SLOT_FIR);
+    const long long want = (long long)D * n * (fir ? s.sz.n_taps : 1);
+    if (n < 1 || want != t.entries) {
+        set_error("%s loaded %d coefficients but MAX_RES_X*MAX_RES_Y*n%s = %d*%d*%d%s = %lld", loader_name(slot), t.entries,
+                  fir ? "*N_TAPS" : "", s.sz.res_x, s.sz.res_y, n, fir ? "*T" : "", want);
+        return false;
+    }
+    L->algo = algo;
+    L->tab.whole = t.whole.p; L->tab.frac = t.frac.p; L->tab.taps = t.taps.p; L->tab.max_whole = t.max_whole;
+    L->n_mics = n; L->n_samples = s.sz.n_samples; L->n_taps = s.sz.n_taps; L->n_dirs = D;
+    L->dir_begin = 0; L->dir_end = D; L->image_stride = D; L->image_origin = 0; L->frames = 1;
+    L->mics = s.d_mics.p;
+    return true;
+}
+
+bool plan_or_error(const bf::DasLaunch& L, bf::DasPlan* plan)
+{
+    const char* why = "";
+    if (bf::plan_das(L, S().n_cus, plan, &why) != 0) { set_error("unsupported shape: %s", why); return false; }
+    return true;
+}
+
+// mimo_* with host pointers: one frame in, one image out (PC/src/algorithms/pad_and_sum.c:100-143 and twins).
+void run_mimo_host(int algo, int slot, const float* signals, float* image, const int* adaptive, int n)
+{
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    sizes_from_env_once();
+    const size_t D = (size_t)s.sz.dirs();
+    if (!signals || !image || !adaptive) { set_error("null argument"); poison(image, image ? D : 0); return; }
+    bool ok = ensure_device();
+    bf::DasLaunch L{};
+    bf::DasPlan plan{};
+    int max_row = 0;
+    ok = ok && upload_mics(adaptive, n, &max_row);
+    ok = ok && describe(algo, slot, n, &L);
+    if (ok) {
+        const size_t rows = (size_t)max_row + 1;
+        L.m_total = (int)rows;
+        ok = HIP_OK(s.d_frame.reserve(rows * s.sz.n_samples)) && HIP_OK(s.d_image.reserve(D));
+        ok = ok && HIP_OK(hipMemcpyAsync(s.d_frame.p, signals, rows * s.sz.n_samples * sizeof(float), hipMemcpyHostToDevice, s.stream));
+        L.signals = s.d_frame.p; L.images = s.d_image.p; L.mics = s.d_mics.p;
+        ok = ok && plan_or_error(L, &plan);
+        ok = ok && HIP_OK(bf::launch_das(L, plan, s.stream));
+        ok = ok && HIP_OK(hipMemcpyAsync(image, s.d_image.p, D * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+        ok = ok && HIP_OK(hipStreamSynchronize(s.stream));
+    }
+    if (!ok) poison(image, D);
+}
+
+// miso_*: one direction (table offset), raw out[N] (pad_and_sum.c:54-70 and twins).
+void run_miso_host(int algo, const TableSet& t, const char* loader, bool fir, const float* signals, float* out,
+                   const int* adaptive, int n, long long row_offset, const float* init)
+{
+    State& s = S();
+    sizes_from_env_once();
+    const size_t N = (size_t)s.sz.n_samples;
+    if (!signals || !out || !adaptive) { set_error("null argument"); poison(out, out ? N : 0); return; }
+    bool ok = ensure_device();
+    bf::DasLaunch L{};
+    bf::DasPlan plan{};
+    int max_row = 0;
+    ok = ok && upload_mics(adaptive, n, &max_row);
+    if (ok) {
+        if (!t.loaded) { set_error("%s has not been called", loader); ok = false; }
+        const long long per = fir ? s.sz.n_taps : 1;
+        if (ok && (row_offset < 0 || (row_offset + n) * per > t.entries)) {
+            set_error("offset %lld + n %d exceeds the %d loaded coefficients", row_offset, n, t.entries);
+            ok = false;
+        }
+        if (ok) {
+            L.algo = algo;
+            L.tab.whole = t.whole.p; L.tab.frac = t.frac.p; L.tab.taps = t.taps.p; L.tab.max_whole = t.max_whole;
+            L.n_mics = n; L.n_samples = s.sz.n_samples; L.n_taps = s.sz.n_taps; L.n_dirs = 1;
+            L.dir_begin = 0; L.dir_end = 1; L.image_stride = 1; L.image_origin = 0; L.frames = 1;
+        }
+    }
+    if (ok) {
+        const size_t rows = (size_t)max_row + 1;
+        L.m_total = (int)rows;
+        ok = HIP_OK(s.d_frame.reserve(rows * N)) && HIP_OK(s.d_out.reserve(N));
+        ok = ok && HIP_OK(hipMemcpyAsync(s.d_frame.p, signals, rows * N * sizeof(float), hipMemcpyHostToDevice, s.stream));
+        if (ok && init) {
+            ok = HIP_OK(s.d_init.reserve(N)) && HIP_OK(hipMemcpyAsync(s.d_init.p, init, N * sizeof(float), hipMemcpyHostToDevice, s.stream));
+        }
+        L.signals = s.d_frame.p; L.images = nullptr; L.mics = s.d_mics.p;
+        ok = ok && plan_or_error(L, &plan);
+        ok = ok && HIP_OK(bf::launch_miso(L, plan, row_offset, init ? s.d_init.p : nullptr, s.d_out.p, s.stream));
+        ok = ok && HIP_OK(hipMemcpyAsync(out, s.d_out.p, N * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+        ok = ok && HIP_OK(hipStreamSynchronize(s.stream));
+    }
+    if (!ok) poison(out, N);
+}
+
+// The single-signal helpers (pad_delay, lerp_delay, convolve_*_delay*): out (+)= delayed(signal).  Run as a
+// one-mic, one-entry-table MISO launch with `out` as the initial accumulator.
+void run_delay_host(int algo, const float* signal, float* out, bool accumulate, int whole, float h, const float* taps)
+{
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    sizes_from_env_once();
+    const size_t N = (size_t)s.sz.n_samples;
+    if (!signal || !out) { set_error("null argument"); poison(out, out ? N : 0); return; }
+    bool ok = ensure_device();
+    if (ok && (whole < 0)) { set_error("negative delay %d", whole); ok = false; }
+    bf::DasLaunch L{};
+    bf::DasPlan plan{};
+    const int zero = 0;
+    int max_row = 0;
+    ok = ok && upload_mics(&zero, 1, &max_row);
+    if (ok) {
+        const int T = s.sz.n_taps;
+        const int w = std::min(whole, s.sz.n_samples);
+        ok = upload(s.d_one_whole, &w, 1) && upload(s.d_one_frac, &h, 1);
+        if (ok && taps) ok = upload(s.d_one_taps, taps, (size_t)T);
+        L.algo = algo;
+        L.tab.whole = s.d_one_whole.p; L.tab.frac = s.d_one_frac.p; L.tab.taps = s.d_one_taps.p; L.tab.max_whole = w;
+        L.n_mics = 1; L.m_total = 1; L.n_samples = s.sz.n_samples; L.n_taps = T; L.n_dirs = 1;
+        L.dir_begin = 0; L.dir_end = 1; L.image_stride = 1; L.image_origin = 0; L.frames = 1;
+    }
+    if (ok) {
+        ok = HIP_OK(s.d_frame.reserve(N)) && HIP_OK(s.d_out.reserve(N)) && HIP_OK(s.d_init.reserve(N));
+        ok = ok && HIP_OK(hipMemcpyAsync(s.d_frame.p, signal, N * sizeof(float), hipMemcpyHostToDevice, s.stream));
+        if (ok && accumulate) ok = HIP_OK(hipMemcpyAsync(s.d_init.p, out, N * sizeof(float), hipMemcpyHostToDevice, s.stream));
+        L.signals = s.d_frame.p; L.mics = s.d_mics.p;
+        ok = ok && plan_or_error(L, &plan);
+        ok = ok && HIP_OK(bf::launch_miso(L, plan, 0, accumulate ? s.d_init.p : nullptr, s.d_out.p, s.stream));
+        ok = ok && HIP_OK(hipMemcpyAsync(out, s.d_out.p, N * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+        ok = ok && HIP_OK(hipStreamSynchronize(s.stream));
+    }
+    if (!ok) poison(out, N);
+}
+
+// Integer table sanity shared by the loaders: no negative delays; values beyond N contribute nothing, so they
+// are clamped to N (keeps the LDS zero prefix bounded).
+bool sanitize_whole(std::vector<int32_t>& w, int n_samples, int* max_whole, const char* who)
+{
+    int mx = 0;
+    for (size_t i = 0; i < w.size(); ++i) {
+        if (w[i] < 0) { set_error("%s: negative delay %d at index %zu (the reference would write out of bounds)", who, w[i], i); return false; }
+        if (w[i] > n_samples) w[i] = n_samples;
+        mx = std::max(mx, w[i]);
+    }
+    *max_whole = mx;
+    return true;
+}
+
+bool load_whole_only(int slot, const int* whole, int n, const char* who)
+{
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    if (!whole || n < 1) { set_error("%s: null or empty table", who); return false; }
+    if (!ensure_device()) return false;
+    std::vector<int32_t> w(whole, whole + n);
+    TableSet& t = s.tab[slot];
+    int mx = 0;
+    if (!sanitize_whole(w, s.sz.n_samples, &mx, who)) return false;
+    if (!upload(t.whole, w.data(), w.size())) return false;
+    t.loaded = true; t.entries = n; t.max_whole = mx;
+    return true;
+}
+
+// hybrid_convolve_and_sum.c:124-157 (note its own pi constant and epsilon placement)
+void hybrid_taps(float* h, double delay, int T)
+{
+    const double PI = 3.14159265359, eps = 1e-9;
+    const double tau = 0.5 - delay + eps;
+    double sum = 0.0;
+    for (int i = 0; i < T; ++i) {
+        double v = (double)i - ((double)T - 1.0) / 2.0 - tau;
+        v = std::sin(v * PI) / (v * PI);
+        const double n = (double)(i * 2 - T + 1);
+        const double w = 0.42 + 0.5 * std::cos(PI * n / ((double)(T - 1)) + eps) + 0.08 * std::cos(2.0 * PI * n / ((double)(T - 1) + eps));
+        v *= w;
+        sum += v;
+        h[i] = (float)v;
+    }
+    for (int i = 0; i < T; ++i) h[i] /= (float)sum;
+}
+
+template <typename F>
+void parallel_for(size_t n, F body)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t workers = std::min<size_t>(hw ? hw : 1, 16);
+    if (n < 65536 || workers < 2) { body(0, n); return; }
+    std::vector<std::thread> pool;
+    const size_t step = (n + workers - 1) / workers;
+    for (size_t w = 0; w < workers; ++w) {
+        const size_t lo = w * step, hi = std::min(n, lo + step);
+        if (lo < hi) pool.emplace_back([=] { body(lo, hi); });
+    }
+    for (auto& th : pool) th.join();
+}
+
+}  // namespace
+
+// ============================================================================================== C-ABI
+extern "C" {
+
+// ---------------------------------------------------------------- configuration / errors
+
+int bf_configure(int n_microphones, int n_samples, int max_res_x, int max_res_y, int n_taps)
+{
+    std::lock_guard<std::mutex> lock(S().mu);
+    S().sizes_from_env_done = true;  // an explicit call wins over $BF_CONFIG
+    return apply_sizes(n_microphones, n_samples, max_res_x, max_res_y, n_taps) ? 0 : -1;
+}
+
+int bf_configure_from_json(const char* path)
+{
+    std::lock_guard<std::mutex> lock(S().mu);
+    S().sizes_from_env_done = true;
+    return (path && configure_from_json(path)) ? 0 : -1;
+}
+
+void bf_get_config(int out[5])
+{
+    std::lock_guard<std::mutex> lock(S().mu);
+    sizes_from_env_once();
+    const Sizes& z = S().sz;
+    out[0] = z.n_microphones; out[1] = z.n_samples; out[2] = z.res_x; out[3] = z.res_y; out[4] = z.n_taps;
+}
+
+const char* bf_last_error(void) { return S().err.c_str(); }
+void bf_clear_error(void) { S().err.clear(); }
+
+int bf_gpu_available(void)
+{
+    int count = 0;
+    return (hipGetDeviceCount(&count) == hipSuccess && count > 0) ? 1 : 0;
+}
+
+int bf_set_device(int device)
+{
+    std::lock_guard<std::mutex> lock(S().mu);
+    if (S().device_ready && device != S().device) { set_error("bf_set_device: device %d already in use", S().device); return -1; }
+    S().device = device;
+    return 0;
+}
+
+// ---------------------------------------------------------------- pad
+
+void load_coefficients_pad(int* whole_samples, int n) { (void)load_whole_only(SLOT_PAD, whole_samples, n, "load_coefficients_pad"); }
+void unload_coefficients_pad(void) { std::lock_guard<std::mutex> lock(S().mu); S().tab[SLOT_PAD].drop(); }
+
+void load_coefficients_pad2(int* whole_miso, int n)
+{
+    std::lock_guard<std::mutex> lock(S().mu);
+    if (!whole_miso || n < 1) { set_error("load_coefficients_pad2: null or empty table"); return; }
+    S().pad2_host.assign(whole_miso, whole_miso + n);
+}
+void unload_coefficients_pad2(void) { std::lock_guard<std::mutex> lock(S().mu); S().pad2_host.clear(); }
+
+void mimo_pad(float* signals, float* image, int* adaptive_array, int n) { run_mimo_host(bf::ALGO_PAD, SLOT_PAD, signals, image, adaptive_array, n); }
+
+void miso_pad(float* signals, float* out, int* adaptive_array, int n, int offset)
+{
+    std::lock_guard<std::mutex> lock(S().mu);
+    run_miso_host(bf::ALGO_PAD, S().tab[SLOT_PAD], loader_name(SLOT_PAD), false, signals, out, adaptive_array, n, offset, nullptr);
+}
+
+void miso_pad2(float* signals, float* out, int* adaptive_array, int n, int offset)
+{
+    // pad_and_sum.c:77-92: delay looked up by MICROPHONE id in the pad2 table; `offset` is unused there too.
+    (void)offset;
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    const size_t N = (size_t)s.sz.n_samples;
+    if (!adaptive_array || n < 1) { set_error("miso_pad2: null or empty adaptive_array"); poison(out, N); return; }
+    std::vector<int32_t> row((size_t)n);
+    for (int m = 0; m < n; ++m) {
+        const int mic = adaptive_array[m];
+        if (mic < 0 || mic >= (int)s.pad2_host.size()) { set_error("miso_pad2: mic %d outside the %zu-entry pad2 table", mic, s.pad2_host.size()); poison(out, N); return; }
+        row[(size_t)m] = s.pad2_host[(size_t)mic];
+    }
+    if (!ensure_device()) { poison(out, N); return; }
+    static TableSet one;  // a private one-row table in slot order
+    int mx = 0;
+    if (!sanitize_whole(row, s.sz.n_samples, &mx, "miso_pad2") || !upload(one.whole, row.data(), row.size())) { poison(out, N); return; }
+    one.loaded = true; one.entries = n; one.max_whole = mx;
+    run_miso_host(bf::ALGO_PAD, one, "load_coefficients_pad2", false, signals, out, adaptive_array, n, 0, nullptr);
+}
+
+void pad_delay(float* signal, float* out, int pos_pad) { run_delay_host(bf::ALGO_PAD, signal, out, true, pos_pad, 0.f, nullptr); }
+
+// ---------------------------------------------------------------- lerp
+
+void load_coefficients_lerp(float* delays, int n)
+{
+    // lerp_and_sum.c:139-153: frac = modf((double)delay, &ip); h = 1.0 - (float)frac (rounded to float); whole = (int)ip
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    if (!delays || n < 1) { set_error("load_coefficients_lerp: null or empty table"); return; }
+    if (!ensure_device()) return;
+    std::vector<int32_t> w((size_t)n);
+    std::vector<float> h((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        double ip;
+        const float frac = (float)std::modf((double)delays[i], &ip);
+        h[(size_t)i] = (float)(1.0 - (double)frac);
+        w[(size_t)i] = (int)ip;
+    }
+    TableSet& t = s.tab[SLOT_LERP];
+    int mx = 0;
+    if (!sanitize_whole(w, s.sz.n_samples, &mx, "load_coefficients_lerp")) return;
+    if (!upload(t.whole, w.data(), w.size()) || !upload(t.frac, h.data(), h.size())) return;
+    t.loaded = true; t.entries = n; t.max_whole = mx;
+}
+void unload_coefficients_lerp(void) { std::lock_guard<std::mutex> lock(S().mu); S().tab[SLOT_LERP].drop(); }
+
+void mimo_lerp(float* signals, float* image, int* adaptive_array, int n) { run_mimo_host(bf::ALGO_LERP, SLOT_LERP, signals, image, adaptive_array, n); }
+void miso_lerp(float* signals, float* out, int* adaptive_array, int n, int offset)
+{
+    std::lock_guard<std::mutex> lock(S().mu);
+    run_miso_host(bf::ALGO_LERP, S().tab[SLOT_LERP], loader_name(SLOT_LERP), false, signals, out, adaptive_array, n, offset, nullptr);
+}
+void lerp_delay(float* signal, float* out, float h, int pad) { run_delay_host(bf::ALGO_LERP, signal, out, true, pad, h, nullptr); }
+
+int bf_get_lerp_tables(int* whole, float* h, int n)
+{
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    const TableSet& t = s.tab[SLOT_LERP];
+    if (!t.loaded || n != t.entries) { set_error("bf_get_lerp_tables: %d requested, %d loaded", n, t.loaded ? t.entries : 0); return -1; }
+    bool ok = HIP_OK(hipMemcpy(whole, t.whole.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    ok = ok && HIP_OK(hipMemcpy(h, t.frac.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return ok ? 0 : -1;
+}
+
+// ---------------------------------------------------------------- convolve (full FIR)
+
+void load_coefficients_convolve(float* h, int n)
+{
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    if (!h || n < 1) { set_error("load_coefficients_convolve: null or empty table"); return; }
+    if (!ensure_device()) return;
+    TableSet& t = s.tab[SLOT_FIR];
+    if (!upload(t.taps, h, (size_t)n)) return;
+    t.loaded = true; t.entries = n; t.max_whole = 0;
+}
+void unload_coefficients_convolve(void) { std::lock_guard<std::mutex> lock(S().mu); S().tab[SLOT_FIR].drop(); }
+
+void mimo_convolve_naive(float* signals, float* image, int* adaptive_array, int n) { run_mimo_host(bf::ALGO_FIR_NAIVE, SLOT_FIR, signals, image, adaptive_array, n); }
+void mimo_convolve_vectorized(float* signals, float* image, int* adaptive_array, int n) { run_mimo_host(bf::ALGO_FIR_VEC, SLOT_FIR, signals, image, adaptive_array, n); }
+
+void miso_convolve_vectorized(float* signals, float* out, int* adaptive_array, int n, int offset)
+{
+    // convolve_and_sum.c:276-292: offset counts taps (d * n * N_TAPS)
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    const int T = s.sz.n_taps;
+    if (offset % T != 0) { set_error("miso_convolve_vectorized: offset %d is not a multiple of N_TAPS=%d", offset, T); poison(out, (size_t)s.sz.n_samples); return; }
+    run_miso_host(bf::ALGO_FIR_VEC, s.tab[SLOT_FIR], loader_name(SLOT_FIR), true, signals, out, adaptive_array, n, offset / T, nullptr);
+}
+
+void convolve_delay_naive_add(float* signal, float* h, float* out) { run_delay_host(bf::ALGO_FIR_NAIVE, signal, out, true, 0, 0.f, h); }
+void convolve_delay_naive(float* signal, float* out, float* h) { run_delay_host(bf::ALGO_FIR_NAIVE, signal, out, true, 0, 0.f, h); }
+void convolve_delay_vectorized(float* signal, float* h, float* out) { run_delay_host(bf::ALGO_FIR_NAIVE, signal, out, false, 0, 0.f, h); }
+void convolve_delay_vectorized_add(float* signal, float* h, float* out) { run_delay_host(bf::ALGO_FIR_VEC, signal, out, true, 0, 0.f, h); }
+
+// ---------------------------------------------------------------- hybrid
+
+void load_coefficients_convolve_hybrid(float* delays, int n)
+{
+    // hybrid_convolve_and_sum.c:161-180
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    if (!delays || n < 1) { set_error("load_coefficients_convolve_hybrid: null or empty table"); return; }
+    if (!ensure_device()) return;
+    const int T = s.sz.n_taps;
+    std::vector<int32_t> w((size_t)n);
+    std::vector<float> taps((size_t)n * T);
+    parallel_for((size_t)n, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            double ip;
+            const double fraction = 1.0 - std::modf((double)delays[i], &ip);
+            w[i] = (int)ip;
+            hybrid_taps(taps.data() + i * T, fraction, T);
+        }
+    });
+    TableSet& t = s.tab[SLOT_HYBRID];
+    int mx = 0;
+    if (!sanitize_whole(w, s.sz.n_samples, &mx, "load_coefficients_convolve_hybrid")) return;
+    if (!upload(t.whole, w.data(), w.size()) || !upload(t.taps, taps.data(), taps.size())) return;
+    t.loaded = true; t.entries = n; t.max_whole = mx;
+}
+void unload_coefficients_convolve_hybrid(void) { std::lock_guard<std::mutex> lock(S().mu); S().tab[SLOT_HYBRID].drop(); }
+
+void mimo_convolve_hybrid(float* signals, float* image, int* adaptive_array, int n) { run_mimo_host(bf::ALGO_HYBRID, SLOT_HYBRID, signals, image, adaptive_array, n); }
+void miso_convolve_hybrid(float* signals, float* out, int* adaptive_array, int n, int offset)
+{
+    std::lock_guard<std::mutex> lock(S().mu);
+    run_miso_host(bf::ALGO_HYBRID, S().tab[SLOT_HYBRID], loader_name(SLOT_HYBRID), false, signals, out, adaptive_array, n, offset, nullptr);
+}
+void convolve_hybrid_delay_add(float* signal, float* h, int pad, float* out) { run_delay_host(bf::ALGO_HYBRID, signal, out, true, pad, 0.f, h); }
+
+int bf_get_hybrid_tables(int* whole, float* taps, int n)
+{
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    const TableSet& t = s.tab[SLOT_HYBRID];
+    if (!t.loaded || n != t.entries) { set_error("bf_get_hybrid_tables: %d requested, %d loaded", n, t.loaded ? t.entries : 0); return -1; }
+    bool ok = HIP_OK(hipMemcpy(whole, t.whole.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    ok = ok && HIP_OK(hipMemcpy(taps, t.taps.p, (size_t)n * s.sz.n_taps * sizeof(float), hipMemcpyDeviceToHost));
+    return ok ? 0 : -1;
+}
+
+// ---------------------------------------------------------------- api.h shims
+
+void bf_publish_frame(const float* signals)
+{
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    sizes_from_env_once();
+    const size_t n = (size_t)s.sz.n_microphones * s.sz.n_samples;
+    if (!signals) { set_error("bf_publish_frame: null frame"); return; }
+    s.published.assign(signals, signals + n);
+}
+
+static bool copy_published(float* out, bool mask_dead)
+{
+    State& s = S();
+    sizes_from_env_once();
+    const size_t n = (size_t)s.sz.n_microphones * s.sz.n_samples;
+    if (s.published.size() != n) { set_error("get_data: no frame published (call bf_publish_frame first)"); poison(out, n); return false; }
+    std::memcpy(out, s.published.data(), n * sizeof(float));
+    if (mask_dead) {
+        if (s.disabled_default) {
+            // PC/src/api.c:835-856 zeroes the rows of the 122 microphones that are dead on the authors' arrays.
+            static const short dead[] = {0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30,
+                31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64,
+                83, 84, 85, 86, 87, 88, 89, 90, 91, 92, 93, 94, 95, 96, 98, 99, 100, 101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111,
+                112, 135, 137, 143, 145, 146, 147, 148, 149, 150, 151, 152, 153, 154, 159, 160, 162, 163, 164, 165, 166, 167, 169, 175,
+                184, 192, 193, 194, 195, 196, 197, 198, 199, 200, 201};
+            s.disabled_mics.assign(dead, dead + sizeof(dead) / sizeof(dead[0]));
+            s.disabled_default = false;
+        }
+        for (int mic : s.disabled_mics)
+            if (mic >= 0 && mic < s.sz.n_microphones) std::memset(out + (size_t)mic * s.sz.n_samples, 0, (size_t)s.sz.n_samples * sizeof(float));
+    }
+    return true;
+}
+
+void get_data(float* signals)
+{
+    std::lock_guard<std::mutex> lock(S().mu);
+    if (signals) (void)copy_published(signals, true);
+}
+
+static void shim(int algo, int slot, float* image, int* adaptive_array, int n, bool mask_dead)
+{
+    std::vector<float> frame;
+    {
+        State& s = S();
+        std::lock_guard<std::mutex> lock(s.mu);
+        sizes_from_env_once();
+        frame.resize((size_t)s.sz.n_microphones * s.sz.n_samples);
+        if (!copy_published(frame.data(), mask_dead)) { poison(image, (size_t)s.sz.dirs()); return; }
+    }
+    run_mimo_host(algo, slot, frame.data(), image, adaptive_array, n);
+}
+
+void pad_mimo(float* image, int* adaptive_array, int n) { shim(bf::ALGO_PAD, SLOT_PAD, image, adaptive_array, n, true); }
+void lerp_mimo(float* image, int* adaptive_array, int n) { shim(bf::ALGO_LERP, SLOT_LERP, image, adaptive_array, n, true); }
+void convolve_mimo_naive(float* image, int* adaptive_array, int n) { shim(bf::ALGO_FIR_NAIVE, SLOT_FIR, image, adaptive_array, n, true); }
+void convolve_mimo_vectorized(float* image, int* adaptive_array, int n) { shim(bf::ALGO_FIR_VEC, SLOT_FIR, image, adaptive_array, n, true); }
+
+void load_coefficients2(int* whole_samples, int n) { (void)load_whole_only(SLOT_TRUNC, whole_samples, n, "load_coefficients2"); }
+// api.c:1077-1087 copies the ring buffer WITHOUT the dead-microphone mask, then runs the pad algorithm
+void mimo_truncated(float* image, int* adaptive_array, int n) { shim(bf::ALGO_PAD, SLOT_TRUNC, image, adaptive_array, n, false); }
+
+void miso_steer_listen(float* out, int* adaptive_array, int n, int steer_offset)
+{
+    std::vector<float> frame;
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    sizes_from_env_once();
+    frame.resize((size_t)s.sz.n_microphones * s.sz.n_samples);
+    if (!copy_published(frame.data(), true)) { poison(out, (size_t)s.sz.n_samples); return; }
+    run_miso_host(bf::ALGO_PAD, s.tab[SLOT_PAD], loader_name(SLOT_PAD), false, frame.data(), out, adaptive_array, n, steer_offset, nullptr);
+}
+
+// ---------------------------------------------------------------- device-resident batched path
+
+int bf_das_device(int algo, const float* d_signals, int m_total, float* d_images, int image_stride, int frames,
+                  const int* adaptive_array, int n, int dir_begin, int dir_end, void* stream)
+{
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    sizes_from_env_once();
+    const int slot = slot_of(algo);
+    if (slot < 0) { set_error("bf_das_device: unknown algo %d", algo); return -1; }
+    if (!d_signals || !d_images || !adaptive_array || frames < 1) { set_error("bf_das_device: null argument or frames < 1"); return -1; }
+    if (!ensure_device()) return -1;
+    int max_row = 0;
+    if (!upload_mics(adaptive_array, n, &max_row)) return -1;
+    if (max_row >= m_total) { set_error("bf_das_device: adaptive_array names row %d but frames have %d rows", max_row, m_total); return -1; }
+    bf::DasLaunch L{};
+    if (!describe(algo, slot, n, &L)) return -1;
+    if (dir_begin < 0 || dir_end > L.n_dirs || dir_begin >= dir_end) { set_error("bf_das_device: bad direction range [%d,%d) of %d", dir_begin, dir_end, L.n_dirs); return -1; }
+    if (image_stride < dir_end - dir_begin) { set_error("bf_das_device: image_stride %d < %d directions", image_stride, dir_end - dir_begin); return -1; }
+    L.signals = d_signals; L.images = d_images; L.m_total = m_total; L.frames = frames;
+    L.dir_begin = dir_begin; L.dir_end = dir_end; L.image_stride = image_stride; L.image_origin = dir_begin;
+    bf::DasPlan plan{};
+    if (!plan_or_error(L, &plan)) return -1;
+    return HIP_OK(bf::launch_das(L, plan, reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
+}
+
+int bf_plan_das(int algo, int n, int frames, int dir_begin, int dir_end, int max_whole, int n_cus, long long out[10])
+{
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    sizes_from_env_once();
+    bf::DasLaunch L{};
+    L.algo = algo; L.n_mics = n; L.m_total = n; L.n_samples = s.sz.n_samples; L.n_taps = s.sz.n_taps; L.n_dirs = s.sz.dirs();
+    L.dir_begin = dir_begin; L.dir_end = dir_end; L.frames = frames; L.tab.max_whole = max_whole;
+    bf::DasPlan p{};
+    const char* why = "";
+    if (bf::plan_das(L, n_cus > 0 ? n_cus : 256, &p, &why) != 0) { set_error("bf_plan_das: %s", why); return -1; }
+    out[0] = p.nc; out[1] = p.lead; out[2] = p.row_stride; out[3] = p.mic_chunk; out[4] = p.n_chunks;
+    out[5] = p.waves; out[6] = p.dpw; out[7] = p.tile_dirs; out[8] = p.n_tiles; out[9] = (long long)p.lds_bytes;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+// Internal interface between the C-ABI layer (beamformer_api.cpp) and the gfx950 kernels (das_kernels.hip).
+// Not installed; the public boundary is include/beamformer_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bf {
+
+// Delay flavours of the reference's four beamformers (PC/src/algorithms/*.c).
+enum Algo : int {
+    ALGO_PAD = 0,        // pad_and_sum.c        integer shift
+    ALGO_LERP = 1,       // lerp_and_sum.c       integer shift + linear interpolation
+    ALGO_HYBRID = 2,     // hybrid_convolve_and_sum.c  integer shift + T-tap fractional FIR
+    ALGO_FIR_NAIVE = 3,  // convolve_and_sum.c   T-tap FIR, sequential tap order (mimo_convolve_naive)
+    ALGO_FIR_VEC = 4,    // convolve_and_sum.c   T-tap FIR, AVX2 lane/tree order  (mimo_convolve_vectorized)
+    ALGO_COUNT = 5
+};
+
+// One steering-table set resident in HBM (what load_coefficients_* uploads).
+struct DeviceTables {
+    const int32_t* whole = nullptr;  // [D][M]      integer delays            (pad, lerp, hybrid)
+    const float* frac = nullptr;     // [D][M]      h = 1 - frac              (lerp)
+    const float* taps = nullptr;     // [D][M][T]   FIR taps                  (hybrid, fir)
+    int max_whole = 0;               // max over the table, clamped to N (sizes the zero prefix in LDS)
+};
+
+// Geometry of one launch.  Directions [dir_begin, dir_end) of every frame in [0, frames).
+struct DasLaunch {
+    const float* signals;    // [frames][m_total][N] device, mic-major (receiver.c:94-151 layout)
+    float* images;           // [frames][image_stride] device; direction d lands at images[f*image_stride + d - image_origin]
+    const int32_t* mics;     // [M] device copy of adaptive_array (row of `signals` for each active slot)
+    DeviceTables tab;
+    int algo;
+    int n_mics;              // M  = n of the reference call
+    int m_total;             // rows in one frame of `signals`
+    int n_samples;           // N
+    int n_taps;              // T
+    int n_dirs;              // D  = MAX_RES_X * MAX_RES_Y
+    int dir_begin, dir_end;  // shard of the direction grid handled by this launch
+    int image_stride, image_origin;
+    int frames;
+};
+
+// Plan chosen on the host for a launch (exposed so tests can check LDS sizing without a GPU).
+struct DasPlan {
+    int nc;          // 64-sample segments per row (N rounded up to 64*nc)
+    int lead;        // zero floats in front of every LDS row
+    int row_stride;  // floats per LDS row
+    int mic_chunk;   // mics staged per pass
+    int n_chunks;
+    int waves;       // waves per workgroup
+    int dpw;         // directions a wave carries across mic chunks
+    int tile_dirs;   // directions per workgroup
+    int n_tiles;     // padded to a multiple of 8 (XCD affinity: tile % 8 == workgroup id % 8)
+    size_t lds_bytes;
+};
+
+// Returns 0 and fills `plan`, or a negative value when the shape is unsupported (message in `why`).
+int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why);
+
+// Enqueue on `stream`; no host synchronisation, no allocation (graph-capturable).
+hipError_t launch_das(const DasLaunch& L, const DasPlan& plan, hipStream_t stream);
+
+// One steered beam -> raw out[N] (miso_pad / miso_lerp / miso_convolve_*).  `row_offset` is the reference's flat
+// table `offset` (d*M); `init_dev` (may be null) seeds the accumulators, which turns the launch into the
+// single-signal helpers `out += delay(signal)` (pad_delay, lerp_delay, convolve_*_delay*).
+hipError_t launch_miso(const DasLaunch& L, const DasPlan& plan, long long row_offset, const float* init_dev, float* out_dev,
+                       hipStream_t stream);
+
+}  // namespace bf

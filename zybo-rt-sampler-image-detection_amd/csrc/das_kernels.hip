@@ -1,0 +1,423 @@
+// das_kernels.hip -- time-domain delay-and-sum beamformers for gfx950 (MI355X, CDNA4, wave64).
+//
+// What one launch computes (reference: PC/src/algorithms/{pad,lerp,convolve,hybrid_convolve}_and_sum.c):
+//   for every frame f and steering direction d:   out_d[k] = sum_m delay_{d,m}( signals[f][mic_m][.] )[k]
+//                                                  image[f][d] = (1/N) * sum_k (out_d[k] / M)^2
+// The reference walks directions, then mics, then samples on one CPU thread.  Here:
+//   * one WORKGROUP owns a tile of directions of one frame and keeps that frame's microphone block in LDS
+//     (mic rows zero-extended on both sides so that a delayed read never needs a bounds test);
+//   * one WAVE owns one direction at a time; lane l owns samples l, l+64, l+128, ... of out_d (registers);
+//   * the per-(direction, mic) delay / interpolation weight / FIR taps are wave-uniform, so they are fetched
+//     with scalar loads (s_load_*) straight from the table row in HBM/L2 -- no VGPR or LDS traffic for tables;
+//   * the inner loop per (direction, mic) is NC conflict-free ds_read_b32 + NC VALU accumulations, in the
+//     reference's mic order and with the reference's operation order, so out_d[k] is bit-identical to the
+//     CPU result; only the final sum over k is a tree (wave reduction) instead of a sequential loop;
+//   * when a frame's mic block does not fit in LDS the mics are staged in chunks and a wave carries DPW
+//     directions' accumulators across the chunks.
+// Workgroup id -> (tile, frame) keeps tile % 8 == id % 8, i.e. all frames' workgroups of one direction tile
+// land on one XCD and re-read that tile's table slice from the XCD's own L2.
+//
+// Roofline: gather-accumulate, no MFMA.  LDS read rate (ds_read_b32: 128 B/clk/CU) bounds it long before HBM;
+// see DESIGN.md for the byte/flop accounting.
+#include "das_kernels.h"
+
+namespace bf {
+
+namespace {
+
+constexpr int kWave = 64;
+
+// Scalars of one launch (kernel argument, lives in SGPRs).
+struct KArgs {
+    long long miso_row;                   // launch_miso only: flat table offset (the reference's `offset`)
+    int n_mics, m_total, n_samples, n_taps;
+    int dir_begin, dir_end, image_stride, image_origin;
+    int lead, row_stride, mic_chunk, n_chunks, tile_dirs, n_tiles;
+    int n_is_pow2;
+    float inv_n;
+};
+
+// The read-only tables are separate `const __restrict__` kernel parameters on purpose: only then can the
+// compiler prove that no store in the kernel clobbers them and fetch the wave-uniform table entries with
+// scalar loads (s_load_*) instead of 64-lane vector loads.
+#define BF_TABLE_PARAMS                                                                                   \
+    const float* __restrict__ signals, float* __restrict__ images, const int32_t* __restrict__ mics,     \
+        const int32_t* __restrict__ whole, const float* __restrict__ frac, const float* __restrict__ taps
+#define BF_TABLE_ARGS signals, images, mics, whole, frac, taps
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+// Copy mic rows [m0, m0+mc) of one frame into LDS rows 0..mc-1 at column `lead`.  One wave per row, lanes
+// stride the row in 16-byte pieces (coalesced global_load_dwordx4 -> ds_write_b128).
+__device__ __forceinline__ void stage_chunk(float* lds, const KArgs& a, const int32_t* __restrict__ mics,
+                                            const float* __restrict__ frame, int m0, int mc, int wave, int nwaves, int lane)
+{
+    const int n = a.n_samples;
+    for (int r = wave; r < mc; r += nwaves) {
+        const int mic = mics[m0 + r];
+        const float* src = frame + (size_t)mic * n;
+        float* dst = lds + r * a.row_stride + a.lead;
+        if ((n & 3) == 0) {
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            float4* d4 = reinterpret_cast<float4*>(dst);
+            for (int i = lane; i < (n >> 2); i += kWave) d4[i] = s4[i];
+        } else {
+            for (int i = lane; i < n; i += kWave) dst[i] = src[i];
+        }
+    }
+}
+
+// Accumulate mics [m0, m0+mc) of the table row starting at flat entry `row_base` (= d*M for direction d)
+// into acc[NC] (lane l holds samples l + 64 c).
+template <int ALGO, int NC>
+__device__ __forceinline__ void accumulate(float (&acc)[NC], const float* lds, const KArgs& a, const int32_t* __restrict__ whole,
+                                           const float* __restrict__ frac, const float* __restrict__ taps, size_t row_base, int m0,
+                                           int mc, int lane)
+{
+    const size_t row = row_base + m0;
+    const int rs = a.row_stride;
+
+    if constexpr (ALGO == ALGO_PAD) {
+        // pad_and_sum.c:41-47,54-70   out[p + i] += s[i]
+        const int32_t* __restrict__ wrow = whole + row;
+#pragma unroll 4
+        for (int ms = 0; ms < mc; ++ms) {
+            const int p = wrow[ms];
+            const float* r = lds + ms * rs + (a.lead - p) + lane;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] += r[c * kWave];
+        }
+    } else if constexpr (ALGO == ALGO_LERP) {
+        // lerp_and_sum.c:50-56,67-92  out[p + i + 1] += s[i] + h * (s[i+1] - s[i]),  0 <= i < N - p - 1
+        const int32_t* __restrict__ wrow = whole + row;
+        const float* __restrict__ hrow = frac + row;
+#pragma unroll 2
+        for (int ms = 0; ms < mc; ++ms) {
+            const int p = wrow[ms];
+            const float h = hrow[ms];
+            const float* r = lds + ms * rs + (a.lead - p - 1) + lane;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float s0 = r[c * kWave];
+                const float s1 = r[c * kWave + 1];
+                float v = __fmaf_rn(h, s1 - s0, s0);      // gcc contracts s0 + h*(s1-s0) into one fma
+                if (c * kWave <= p) v = (lane + c * kWave > p) ? v : 0.0f;   // i >= 0 only (wave-uniform guard)
+                acc[c] += v;
+            }
+        }
+    } else if constexpr (ALGO == ALGO_HYBRID) {
+        // hybrid_convolve_and_sum.c:51-64  out[p + i + 1] += h[t] * padded[i + t], t = 0..T-1 in order
+        const int T = a.n_taps;
+        const int32_t* __restrict__ wrow = whole + row;
+        const float* __restrict__ trow = taps + row * T;
+        for (int ms = 0; ms < mc; ++ms) {
+            const int p = wrow[ms];
+            const float* __restrict__ h = trow + ms * T;
+            const float* r = lds + ms * rs + (a.lead - p - 1 - T / 2) + lane;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float o = acc[c];
+                if (c * kWave <= p) {
+                    // this segment contains samples with i < 0: they must not receive anything
+                    const bool live = lane + c * kWave > p;
+                    for (int t = 0; t < T; ++t) o = live ? __fmaf_rn(h[t], r[c * kWave + t], o) : o;
+                } else {
+                    for (int t = 0; t < T; ++t) o = __fmaf_rn(h[t], r[c * kWave + t], o);
+                }
+                acc[c] = o;
+            }
+        }
+    } else if constexpr (ALGO == ALGO_FIR_NAIVE) {
+        // convolve_and_sum.c:197-211  out[i] += h[t] * padded[i + t], t in order (fma chain into out)
+        const int T = a.n_taps;
+        const float* __restrict__ trow = taps + row * T;
+        for (int ms = 0; ms < mc; ++ms) {
+            const float* __restrict__ h = trow + ms * T;
+            const float* r = lds + ms * rs + (a.lead - T / 2) + lane;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float o = acc[c];
+                for (int t = 0; t < T; ++t) o = __fmaf_rn(h[t], r[c * kWave + t], o);
+                acc[c] = o;
+            }
+        }
+    } else {  // ALGO_FIR_VEC
+        // convolve_and_sum.c:158-192 + sum8 :132-153: 8 independent fma lanes over tap blocks, fixed tree, out +=
+        const int T = a.n_taps;
+        const float* __restrict__ trow = taps + row * T;
+        for (int ms = 0; ms < mc; ++ms) {
+            const float* __restrict__ h = trow + ms * T;
+            const float* r = lds + ms * rs + (a.lead - T / 2) + lane;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f, l4 = 0.f, l5 = 0.f, l6 = 0.f, l7 = 0.f;
+                for (int t = 0; t < T; t += 8) {
+                    const float* x = r + c * kWave + t;
+                    l0 = __fmaf_rn(x[0], h[t + 0], l0); l1 = __fmaf_rn(x[1], h[t + 1], l1);
+                    l2 = __fmaf_rn(x[2], h[t + 2], l2); l3 = __fmaf_rn(x[3], h[t + 3], l3);
+                    l4 = __fmaf_rn(x[4], h[t + 4], l4); l5 = __fmaf_rn(x[5], h[t + 5], l5);
+                    l6 = __fmaf_rn(x[6], h[t + 6], l6); l7 = __fmaf_rn(x[7], h[t + 7], l7);
+                }
+                const float q0 = l0 + l4, q1 = l1 + l5, q2 = l2 + l6, q3 = l3 + l7;
+                const float d0 = q0 + q2, d1 = q1 + q3;
+                acc[c] += d0 + d1;
+            }
+        }
+    }
+}
+
+// Mean power of one direction from the lane-distributed out_d (pad_and_sum.c:122-131).
+template <int NC>
+__device__ __forceinline__ float direction_power(const float (&acc)[NC], const KArgs& a, int lane)
+{
+    float part = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        // out[k] /= (float)n: a power-of-two n makes the reciprocal multiply exact; otherwise divide.
+        const float o = a.n_is_pow2 ? acc[c] * a.inv_n : acc[c] / (float)a.n_mics;
+        const float sq = (lane + c * kWave < a.n_samples) ? o * o : 0.0f;
+        part += sq;
+    }
+    return wave_sum(part) / (float)a.n_samples;
+}
+
+template <int ALGO, int NC, int DPW>
+__global__ void __launch_bounds__(1024) das_mimo_kernel(BF_TABLE_PARAMS, KArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = (int)(blockDim.x >> 6);
+    const int tile = (int)(blockIdx.x % (unsigned)a.n_tiles);
+    const int frame = (int)(blockIdx.x / (unsigned)a.n_tiles);
+    const int tile_begin = a.dir_begin + tile * a.tile_dirs;
+    if (tile_begin >= a.dir_end) return;  // padding tile (n_tiles is rounded up to a multiple of 8)
+    const int tile_end = min(tile_begin + a.tile_dirs, a.dir_end);
+
+    // zero the whole LDS image once: the lead/tail columns and unused rows stay zero for the kernel's lifetime
+    {
+        const int total4 = (a.mic_chunk * a.row_stride) >> 2;
+        float4* z = reinterpret_cast<float4*>(lds);
+        for (int i = threadIdx.x; i < total4; i += blockDim.x) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+
+    const float* __restrict__ frame_sig = signals + (size_t)frame * a.m_total * a.n_samples;
+    float* __restrict__ img = images + (size_t)frame * a.image_stride;
+    const int group = nwaves * DPW;
+
+    for (int g0 = tile_begin; g0 < tile_end; g0 += group) {
+        float acc[DPW][NC];
+#pragma unroll
+        for (int j = 0; j < DPW; ++j)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[j][c] = 0.0f;
+
+        for (int ch = 0; ch < a.n_chunks; ++ch) {
+            const int m0 = ch * a.mic_chunk;
+            const int mc = min(a.mic_chunk, a.n_mics - m0);
+            if (a.n_chunks > 1 || g0 == tile_begin) {
+                if (a.n_chunks > 1 && (ch > 0 || g0 != tile_begin)) __syncthreads();  // previous readers done
+                stage_chunk(lds, a, mics, frame_sig, m0, mc, wave, nwaves, lane);
+                __syncthreads();
+            }
+#pragma unroll
+            for (int j = 0; j < DPW; ++j) {
+                const int d = g0 + j * nwaves + wave;  // wave-uniform
+                if (d < tile_end) accumulate<ALGO, NC>(acc[j], lds, a, whole, frac, taps, (size_t)d * a.n_mics, m0, mc, lane);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            const int d = g0 + j * nwaves + wave;
+            if (d < tile_end) {
+                const float pw = direction_power<NC>(acc[j], a, lane);
+                if (lane == 0) img[d - a.image_origin] = pw;
+            }
+        }
+    }
+}
+
+// One direction, raw out[N] (no division): miso_pad / miso_lerp / miso_convolve_* (pad_and_sum.c:54-70 ...).
+template <int ALGO, int NC>
+__global__ void __launch_bounds__(64) das_miso_kernel(BF_TABLE_PARAMS, const float* __restrict__ miso_init, float* __restrict__ miso_out, KArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & (kWave - 1);
+    {
+        const int total4 = (a.mic_chunk * a.row_stride) >> 2;
+        float4* z = reinterpret_cast<float4*>(lds);
+        for (int i = threadIdx.x; i < total4; i += blockDim.x) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    float acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        acc[c] = (miso_init != nullptr && lane + c * kWave < a.n_samples) ? miso_init[lane + c * kWave] : 0.0f;
+    for (int ch = 0; ch < a.n_chunks; ++ch) {
+        const int m0 = ch * a.mic_chunk;
+        const int mc = min(a.mic_chunk, a.n_mics - m0);
+        if (ch > 0) __syncthreads();
+        stage_chunk(lds, a, mics, signals, m0, mc, 0, 1, lane);
+        __syncthreads();
+        accumulate<ALGO, NC>(acc, lds, a, whole, frac, taps, (size_t)a.miso_row, m0, mc, lane);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        if (lane + c * kWave < a.n_samples) miso_out[lane + c * kWave] = acc[c];
+}
+
+template <int ALGO, int NC>
+hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, int frames, hipStream_t stream)
+{
+    const dim3 grid((unsigned)plan.n_tiles * (unsigned)frames);
+    const dim3 block((unsigned)plan.waves * kWave);
+    auto go = [&](auto kernel) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)plan.lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kernel, grid, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole, L.tab.frac, L.tab.taps, a);
+        return hipGetLastError();
+    };
+    switch (plan.dpw) {
+        case 1: return go(das_mimo_kernel<ALGO, NC, 1>);
+        case 2: return go(das_mimo_kernel<ALGO, NC, 2>);
+        case 4: return go(das_mimo_kernel<ALGO, NC, 4>);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int ALGO>
+hipError_t launch_algo(const DasLaunch& L, const KArgs& a, const DasPlan& plan, int frames, hipStream_t stream)
+{
+    switch (plan.nc) {
+        case 1: return launch_nc<ALGO, 1>(L, a, plan, frames, stream);
+        case 2: return launch_nc<ALGO, 2>(L, a, plan, frames, stream);
+        case 4: return launch_nc<ALGO, 4>(L, a, plan, frames, stream);
+        case 8: return launch_nc<ALGO, 8>(L, a, plan, frames, stream);
+        case 16: return launch_nc<ALGO, 16>(L, a, plan, frames, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int ALGO>
+hipError_t launch_miso_algo(const DasLaunch& L, const KArgs& a, const DasPlan& plan, const float* init_dev, float* out_dev, hipStream_t stream)
+{
+    auto go = [&](auto kernel) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)plan.lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kernel, dim3(1), dim3(kWave), plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole, L.tab.frac, L.tab.taps,
+                           init_dev, out_dev, a);
+        return hipGetLastError();
+    };
+    switch (plan.nc) {
+        case 1: return go(das_miso_kernel<ALGO, 1>);
+        case 2: return go(das_miso_kernel<ALGO, 2>);
+        case 4: return go(das_miso_kernel<ALGO, 4>);
+        case 8: return go(das_miso_kernel<ALGO, 8>);
+        case 16: return go(das_miso_kernel<ALGO, 16>);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+KArgs make_args(const DasLaunch& L, const DasPlan& plan)
+{
+    KArgs a{};
+    a.miso_row = 0;
+    a.n_mics = L.n_mics; a.m_total = L.m_total; a.n_samples = L.n_samples; a.n_taps = L.n_taps;
+    a.dir_begin = L.dir_begin; a.dir_end = L.dir_end; a.image_stride = L.image_stride; a.image_origin = L.image_origin;
+    a.lead = plan.lead; a.row_stride = plan.row_stride; a.mic_chunk = plan.mic_chunk; a.n_chunks = plan.n_chunks;
+    a.tile_dirs = plan.tile_dirs; a.n_tiles = plan.n_tiles;
+    a.n_is_pow2 = (L.n_mics & (L.n_mics - 1)) == 0;
+    a.inv_n = 1.0f / (float)L.n_mics;
+    return a;
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
+{
+    static const char* kWhy[] = {"", "N_SAMPLES must be in [1, 1024]", "N_TAPS must be in [1, 64] (multiple of 8 for the vectorized FIR)",
+                                 "one microphone row does not fit in LDS", "empty launch"};
+    auto fail = [&](int i) { if (why) *why = kWhy[i]; return -i; };
+    if (L.n_samples < 1 || L.n_samples > 1024) return fail(1);
+    const bool fir = L.algo == ALGO_HYBRID || L.algo == ALGO_FIR_NAIVE || L.algo == ALGO_FIR_VEC;
+    if (fir && (L.n_taps < 1 || L.n_taps > 64 || (L.algo == ALGO_FIR_VEC && (L.n_taps % 8) != 0))) return fail(2);
+    if (L.n_mics < 1 || L.frames < 1 || L.dir_end <= L.dir_begin) return fail(4);
+
+    DasPlan p{};
+    int nc = (L.n_samples + kWave - 1) / kWave;
+    p.nc = nc <= 1 ? 1 : nc <= 2 ? 2 : nc <= 4 ? 4 : nc <= 8 ? 8 : 16;
+    const int T = fir ? L.n_taps : 0;
+    const int shift = (L.algo == ALGO_FIR_NAIVE || L.algo == ALGO_FIR_VEC) ? 0 : L.tab.max_whole;
+    p.lead = round_up(shift + 1 + T / 2, 4);
+    const int tail = round_up(T, 4);
+    p.row_stride = p.lead + p.nc * kWave + tail;
+    const size_t row_bytes = (size_t)p.row_stride * sizeof(float);
+
+    // Whole mic block resident: two workgroups per CU (<= 80 KiB each).  Otherwise one 156 KiB workgroup per CU
+    // stages the mics in chunks and every wave carries DPW directions across the chunks.
+    const size_t small_budget = 80 * 1024, big_budget = 156 * 1024;
+    if (row_bytes * (size_t)L.n_mics <= small_budget) {
+        p.mic_chunk = L.n_mics; p.n_chunks = 1; p.waves = 8; p.dpw = 1;
+    } else {
+        int mc = (int)(big_budget / row_bytes);
+        if (mc < 1) return fail(3);
+        if (mc >= 4) mc &= ~3;
+        if (mc > L.n_mics) mc = L.n_mics;
+        p.mic_chunk = mc; p.n_chunks = (L.n_mics + mc - 1) / mc;
+        p.waves = 16; p.dpw = p.n_chunks > 1 ? 4 : 1;
+    }
+    p.lds_bytes = row_bytes * (size_t)p.mic_chunk;
+
+    // Tile size: enough workgroups to fill the chip a few times over, but as many directions per staged block
+    // as possible.  A tile is a whole number of wave groups.
+    const int group = p.waves * p.dpw;
+    const long long dirs = (long long)(L.dir_end - L.dir_begin);
+    const long long target_wgs = (long long)n_cus * 4;
+    long long td = (dirs * L.frames + target_wgs - 1) / target_wgs;
+    td = round_up((int)(td < group ? group : td > 512 ? 512 : td), group);
+    p.tile_dirs = (int)td;
+    p.n_tiles = round_up((int)((dirs + td - 1) / td), 8);
+    *plan = p;
+    if (why) *why = kWhy[0];
+    return 0;
+}
+
+hipError_t launch_das(const DasLaunch& L, const DasPlan& plan, hipStream_t stream)
+{
+    const KArgs a = make_args(L, plan);
+    switch (L.algo) {
+        case ALGO_PAD: return launch_algo<ALGO_PAD>(L, a, plan, L.frames, stream);
+        case ALGO_LERP: return launch_algo<ALGO_LERP>(L, a, plan, L.frames, stream);
+        case ALGO_HYBRID: return launch_algo<ALGO_HYBRID>(L, a, plan, L.frames, stream);
+        case ALGO_FIR_NAIVE: return launch_algo<ALGO_FIR_NAIVE>(L, a, plan, L.frames, stream);
+        case ALGO_FIR_VEC: return launch_algo<ALGO_FIR_VEC>(L, a, plan, L.frames, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_miso(const DasLaunch& L, const DasPlan& plan, long long row_offset, const float* init_dev, float* out_dev,
+                       hipStream_t stream)
+{
+    KArgs a = make_args(L, plan);
+    a.miso_row = row_offset;
+    switch (L.algo) {
+        case ALGO_PAD: return launch_miso_algo<ALGO_PAD>(L, a, plan, init_dev, out_dev, stream);
+        case ALGO_LERP: return launch_miso_algo<ALGO_LERP>(L, a, plan, init_dev, out_dev, stream);
+        case ALGO_HYBRID: return launch_miso_algo<ALGO_HYBRID>(L, a, plan, init_dev, out_dev, stream);
+        case ALGO_FIR_NAIVE: return launch_miso_algo<ALGO_FIR_NAIVE>(L, a, plan, init_dev, out_dev, stream);
+        case ALGO_FIR_VEC: return launch_miso_algo<ALGO_FIR_VEC>(L, a, plan, init_dev, out_dev, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace bf
