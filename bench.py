@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- beam-steered frames/s of the delay-and-sum hot path on MI355X (BASELINE.json metric).
+
+One STEP = one batched launch of the hot path over `--frames` synthetic 64-mic x 256-sample windows
+(190 windows = one second of audio at 48828 Hz, PC/src/config.json:4,16), every window steered to all
+101 x 101 directions (BASELINE.json configs[1]).  Inputs and tables are resident in HBM before the timed region.
+
+  python bench.py [--gpus N --steps K --warmup W]      (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+N > 1 (north_star): the direction grid is sharded over the ranks, every rank steers ALL
+frames of the (N x larger) global batch to its own contiguous shard of directions -- per-GPU work is fixed, i.e.
+weak scaling -- and one RCCL all-gather per step assembles the full heat-maps on every rank.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "zybo-rt-sampler-image-detection_amd")
+sys.path.insert(0, PKG)
+
+WORKLOADS = {
+    # name: (N_MICROPHONES, tiles, N_SAMPLES, MAX_RES_X, MAX_RES_Y, N_TAPS)
+    "cfg1": (64, 1, 256, 11, 11, 8),
+    "cfg2": (64, 1, 256, 101, 101, 8),
+    "shipped": (256, 4, 256, 57, 32, 8),
+    "cfg5": (256, 4, 1024, 361, 361, 8),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+LDS_PEAK_GBS = 128 * 256 * 2.4  # ds_read_b32: 128 B/clk/CU x 256 CUs x 2.4 GHz = 78.6 TB/s
+
+
+def algorithmic_bytes_per_frame(algo, M, N, D, T):
+    """signals + tables + image."""
+    sig, img = 4 * M * N, 4 * D
+    return {"pad": sig + 4 * D * M + img, "lerp": sig + 8 * D * M + img, "hybrid": sig + 4 * D * M * (1 + T) + img,
+            "fir_vec": sig + 4 * D * M * T + img, "fir_naive": sig + 4 * D * M * T + img}[algo]
+
+
+def cpu_baseline(workload, algo, budget_s=12.0):
+    """The reference's own C (oracle/_ref, built by oracle/build_ref.py) -- or, if absent, the oracle port -- timed
+    on ONE host core (the reference runs a single producer process, PC/src/main.pyx:699) on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import das_oracle
+    import directions_np as D
+    import synth
+    M, tiles, N, X, Y, T = WORKLOADS[workload]
+    if das_oracle.RefLib.available(workload):
+        eng = das_oracle.RefLib(workload)
+    else:
+        eng = das_oracle.Oracle(N, X, Y, T)
+    delays = D.calculate_delays(X, Y, arrays=tiles)
+    mics = np.arange(M, dtype=np.int32)
+    table = D.whole_samples(delays) if algo == "pad" else np.float32(delays)
+    run = {"pad": eng.mimo_pad, "lerp": eng.mimo_lerp, "hybrid": eng.mimo_hybrid}[algo]
+    sig = synth.s2_noise(M, N, seed=100)
+    run(sig, table, mics)                      # warm-up (also loads the table)
+    # time the kernel only: tables stay loaded, as in the live loop (PC/src/main.pyx:172-199)
+    fn = getattr(eng.lib, eng.pre + {"pad": "mimo_pad", "lerp": "mimo_lerp", "hybrid": "mimo_convolve_hybrid"}[algo])
+    img = np.zeros(X * Y, dtype=np.float32)
+    args = (das_oracle._f(sig), das_oracle._f(img), das_oracle._i(mics), C.c_int(M))
+    if hasattr(eng, "_fn"):
+        eng._fn("mimo_pad")
+    t0 = time.perf_counter()
+    frames = 0
+    while True:
+        fn(*args)
+        frames += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or frames >= 400:
+            break
+    return {"value": frames / el, "unit": "frames/s", "cores": 1, "kind": eng.kind,
+            "sample": "%d frames of %s (%s, S2 noise), kernel only, tables preloaded, %.1f s" % (frames, workload, algo, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=190, help="windows per GPU per step")
+    ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
+    ap.add_argument("--algo", default="lerp", choices=["pad", "lerp", "hybrid", "fir_vec", "fir_naive"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from interface import config
+    from lib import _native as nat
+    from lib import directions
+    import synth
+    import multi_gpu
+
+    M, tiles, N, X, Y, T = WORKLOADS[args.workload]
+    D = X * Y
+    if nat.lib.bf_set_device(local_rank) != 0:
+        nat.check()
+    config.configure(N_MICROPHONES=M, ACTIVE_TILES=tiles, N_SAMPLES=N, MAX_RES_X=X, MAX_RES_Y=Y, N_TAPS=T)
+
+    # ---- tables (once, outside the timed region -- as the reference's producer loops do)
+    delays = directions.calculate_delays()
+    mics = np.ascontiguousarray(directions.active_microphones()[0].astype(np.int32))
+    algo_id = {"pad": nat.PAD, "lerp": nat.LERP, "hybrid": nat.HYBRID, "fir_vec": nat.FIR_VEC, "fir_naive": nat.FIR_NAIVE}[args.algo]
+    if args.algo == "pad":
+        t = np.ascontiguousarray(delays.astype(int).astype(np.int32)).ravel()
+        nat.lib.load_coefficients_pad(nat.iptr(t), t.size)
+    elif args.algo == "lerp":
+        t = np.ascontiguousarray(np.float32(delays)).ravel()
+        nat.lib.load_coefficients_lerp(nat.fptr(t), t.size)
+    elif args.algo == "hybrid":
+        t = np.ascontiguousarray(np.float32(delays)).ravel()
+        nat.lib.load_coefficients_convolve_hybrid(nat.fptr(t), t.size)
+    else:
+        t = directions.compute_convolve_h().ravel()
+        nat.lib.load_coefficients_convolve(nat.fptr(t), t.size)
+    nat.check()
+
+    # ---- synthetic input resident in HBM: the GLOBAL batch on every rank (direction sharding broadcasts frames)
+    frames_global = args.frames * world
+    host = synth.frame_batch(M, N, min(frames_global, 64))          # 64 distinct windows, tiled to the batch size
+    reps = (frames_global + host.shape[0] - 1) // host.shape[0]
+    d_sig = torch.from_numpy(np.tile(host, (reps, 1, 1))[:frames_global]).to(dev)
+    lo, hi = multi_gpu.shard_range(D, world, rank)
+    shard_cap = multi_gpu.shard_capacity(D, world)
+    d_part = torch.zeros((frames_global, shard_cap), dtype=torch.float32, device=dev)
+    d_full = torch.zeros((world * frames_global, shard_cap), dtype=torch.float32, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream()
+
+    def step():
+        rc = nat.lib.bf_das_device(algo_id, d_sig.data_ptr(), M, d_part.data_ptr(), shard_cap, frames_global, nat.iptr(mics), M,
+                                   lo, hi, stream.cuda_stream)
+        if rc != 0:
+            nat.check()
+        if world > 1:
+            dist.all_gather_into_tensor(d_full, d_part)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        # HIP events on the launch stream bracket the beamforming kernel only (not the collective)
+        ev[k][0].record(stream)
+        rc = nat.lib.bf_das_device(algo_id, d_sig.data_ptr(), M, d_part.data_ptr(), shard_cap, frames_global, nat.iptr(mics), M,
+                                   lo, hi, stream.cuda_stream)
+        ev[k][1].record(stream)
+        if rc != 0:
+            nat.check()
+        if world > 1:
+            dist.all_gather_into_tensor(d_full, d_part)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    assert torch.isfinite(d_part[:, : hi - lo]).all(), "non-finite beam power"
+
+    if rank == 0:
+        fps = frames_global * args.steps / elapsed
+        # per-launch algorithmic bytes of THIS rank's kernel: all frames, its direction shard
+        share = (hi - lo) / D
+        bytes_frame = algorithmic_bytes_per_frame(args.algo, M, N, D, T)
+        sig_bytes = 4 * M * N
+        alg_bytes = frames_global * (sig_bytes + (bytes_frame - sig_bytes) * share)
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        macs = frames_global * (hi - lo) * M * N
+        lds_bytes = macs * 4 * (2 if args.algo == "lerp" else T if args.algo in ("hybrid", "fir_vec", "fir_naive") else 1)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            rec = json.load(open(tpath)).get("%s_%s_f%d_n%d" % (args.workload, args.algo, args.frames, world))
+            traffic = rec["hbm_bytes_per_launch"] if rec else None
+        line = {
+            "metric": "beam-steered frames/sec (64 mics x 256 samples x 101x101 angles)" if args.workload == "cfg2" else "beam-steered frames/sec",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d mics x %d samples x %dx%d directions, delay-and-sum (%s), %d frames/GPU/step"
+                                   % (args.workload, M, N, X, Y, args.algo, args.frames),
+                       "frames_per_step_global": frames_global, "directions_per_gpu": hi - lo,
+                       "parallelism": "directions sharded over %d GPU(s) + RCCL all-gather of the heat-maps" % world if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "das_mimo_kernel<%s>" % args.algo, "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "table/LDS-gather kernel: the binding resource is LDS read bandwidth, not HBM (DESIGN.md section 5)",
+                         "lds": {"achieved": lds_bytes / (kernel_ms * 1e-3) / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
+                                 "frac": lds_bytes / (kernel_ms * 1e-3) / 1e9 / LDS_PEAK_GBS},
+                         "gmacs_per_s": macs / (kernel_ms * 1e-3) / 1e9},
+        }
+        if world == 1 and not args.no_cpu_baseline and args.algo in ("pad", "lerp", "hybrid"):
+            line["cpu_baseline"] = cpu_baseline(args.workload, args.algo)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -58,7 +58,13 @@ def test_wrappers_match_golden(nat, name, algo, sig):
     assert got.shape == want.shape and got.dtype == np.float32
     assert np.isfinite(got).all()
     assert max_rel(got, want) <= REL_TOL
-    assert np.unravel_index(np.argmax(got), got.shape) == np.unravel_index(np.argmax(want), want.shape)
+    if algo != "convolve" or name == "cfg1":
+        # stronger than the bar: the kernels keep the reference's operation order end to end (mic order, fma
+        # placement, k-ordered power sum), so the maps are bit-identical to the compiled reference's
+        assert got.tobytes() == want.tobytes()
+    top = np.sort(want.ravel())[-2:]
+    if top[1] - top[0] > 4 * REL_TOL * top[1]:        # the peak is unambiguous at the tolerance: it must be in the same pixel
+        assert np.unravel_index(np.argmax(got), got.shape) == np.unravel_index(np.argmax(want), want.shape)
 
 
 def test_known_answer_tone(nat):

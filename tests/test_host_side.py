@@ -68,7 +68,7 @@ def test_plan_geometry(native):
     util.configure("cfg2")
     assert native.lib.bf_plan_das(native.LERP, 64, 190, 0, 101 * 101, 12, 256, out) == 0
     nc, lead, rs, mc, nch, waves, dpw, tile, ntiles, lds = list(out)
-    assert nc == 4 and mc == 64 and nch == 1 and dpw == 1 and lds <= 80 * 1024 and ntiles % 8 == 0 and lead >= 13
+    assert nc == 4 and mc == 64 and nch == 1 and dpw == 1 and waves == 16 and lds <= 160 * 1024 and ntiles % 8 == 0 and lead >= 13
     util.configure("cfg5")
     assert native.lib.bf_plan_das(native.LERP, 256, 1, 0, 361 * 361, 47, 256, out) == 0
     nc, lead, rs, mc, nch, waves, dpw, tile, ntiles, lds = list(out)

@@ -49,6 +49,9 @@ struct DasPlan {
     int mic_chunk;   // mics staged per pass
     int n_chunks;
     int waves;       // waves per workgroup
+    int scratch_off; // float offset of the per-wave power scratch in LDS
+    int srow;        // scratch row stride in floats (odd: 64*nc + 1)
+    int pbw;         // scratch rows (finished directions) per wave
     int dpw;         // directions a wave carries across mic chunks
     int tile_dirs;   // directions per workgroup
     int n_tiles;     // padded to a multiple of 8 (XCD affinity: tile % 8 == workgroup id % 8)

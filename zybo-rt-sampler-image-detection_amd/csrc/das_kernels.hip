@@ -33,6 +33,7 @@ struct KArgs {
     int n_mics, m_total, n_samples, n_taps;
     int dir_begin, dir_end, image_stride, image_origin;
     int lead, row_stride, mic_chunk, n_chunks, tile_dirs, n_tiles;
+    int scratch_off, srow, pbw;           // per-wave power scratch: float offset in LDS, row stride, rows per wave
     int n_is_pow2;
     float inv_n;
 };
@@ -171,19 +172,35 @@ __device__ __forceinline__ void accumulate(float (&acc)[NC], const float* lds, c
     }
 }
 
-// Mean power of one direction from the lane-distributed out_d (pad_and_sum.c:122-131).
+// ---- mean power, in the reference's summation order ------------------------------------------------------
+// The reference finishes a direction with (pad_and_sum.c:122-131)
+//     for k: out[k] /= n; sum += out[k]^2          (gcc: vdivps, vmulps, then one vaddss per k, in k order)
+//     image = sum / N
+// A float32 sum of N squares taken in another order differs from that by up to ~N*2^-24 relative (2e-5 observed
+// at N = 1024), which is more than the 1e-5 parity bar.  So the squares are summed in k order here too:
+// every wave parks the squares of `pbw` finished directions as rows of a private LDS scratch, then lanes
+// 0..pbw-1 each walk one row front to back.  Row stride is odd, so the lanes' reads never share a bank.
 template <int NC>
-__device__ __forceinline__ float direction_power(const float (&acc)[NC], const KArgs& a, int lane)
+__device__ __forceinline__ void park_squares(const float (&acc)[NC], float* scratch_row, const KArgs& a, int d, int lane)
 {
-    float part = 0.0f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        // out[k] /= (float)n: a power-of-two n makes the reciprocal multiply exact; otherwise divide.
+        // out[k] /= (float)n: for a power-of-two n the reciprocal multiply is exact; otherwise a true division
         const float o = a.n_is_pow2 ? acc[c] * a.inv_n : acc[c] / (float)a.n_mics;
-        const float sq = (lane + c * kWave < a.n_samples) ? o * o : 0.0f;
-        part += sq;
+        if (lane + c * kWave < a.n_samples) scratch_row[lane + c * kWave] = o * o;
     }
-    return wave_sum(part) / (float)a.n_samples;
+    if (lane == 0) scratch_row[a.srow - 1] = __int_as_float(d);   // the pad column carries the direction id
+}
+
+__device__ __forceinline__ void flush_powers(const float* scratch, int filled, float* __restrict__ img, const KArgs& a, int lane)
+{
+    if (lane < filled) {
+        const float* row = scratch + lane * a.srow;
+        float sum = 0.0f;
+        for (int k = 0; k < a.n_samples; ++k) sum += row[k];
+        const int d = __float_as_int(row[a.srow - 1]);
+        img[d - a.image_origin] = sum / (float)a.n_samples;
+    }
 }
 
 template <int ALGO, int NC, int DPW>
@@ -210,6 +227,8 @@ __global__ void __launch_bounds__(1024) das_mimo_kernel(BF_TABLE_PARAMS, KArgs a
     const float* __restrict__ frame_sig = signals + (size_t)frame * a.m_total * a.n_samples;
     float* __restrict__ img = images + (size_t)frame * a.image_stride;
     const int group = nwaves * DPW;
+    float* scratch = lds + a.scratch_off + wave * (a.pbw * a.srow);
+    int filled = 0;   // wave-uniform
 
     for (int g0 = tile_begin; g0 < tile_end; g0 += group) {
         float acc[DPW][NC];
@@ -236,11 +255,12 @@ __global__ void __launch_bounds__(1024) das_mimo_kernel(BF_TABLE_PARAMS, KArgs a
         for (int j = 0; j < DPW; ++j) {
             const int d = g0 + j * nwaves + wave;
             if (d < tile_end) {
-                const float pw = direction_power<NC>(acc[j], a, lane);
-                if (lane == 0) img[d - a.image_origin] = pw;
+                park_squares<NC>(acc[j], scratch + filled * a.srow, a, d, lane);
+                if (++filled == a.pbw) { flush_powers(scratch, filled, img, a, lane); filled = 0; }
             }
         }
     }
+    if (filled > 0) flush_powers(scratch, filled, img, a, lane);
 }
 
 // One direction, raw out[N] (no division): miso_pad / miso_lerp / miso_convolve_* (pad_and_sum.c:54-70 ...).
@@ -334,6 +354,7 @@ KArgs make_args(const DasLaunch& L, const DasPlan& plan)
     a.dir_begin = L.dir_begin; a.dir_end = L.dir_end; a.image_stride = L.image_stride; a.image_origin = L.image_origin;
     a.lead = plan.lead; a.row_stride = plan.row_stride; a.mic_chunk = plan.mic_chunk; a.n_chunks = plan.n_chunks;
     a.tile_dirs = plan.tile_dirs; a.n_tiles = plan.n_tiles;
+    a.scratch_off = plan.scratch_off; a.srow = plan.srow; a.pbw = plan.pbw;
     a.n_is_pow2 = (L.n_mics & (L.n_mics - 1)) == 0;
     a.inv_n = 1.0f / (float)L.n_mics;
     return a;
@@ -363,20 +384,28 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
     p.row_stride = p.lead + p.nc * kWave + tail;
     const size_t row_bytes = (size_t)p.row_stride * sizeof(float);
 
-    // Whole mic block resident: two workgroups per CU (<= 80 KiB each).  Otherwise one 156 KiB workgroup per CU
-    // stages the mics in chunks and every wave carries DPW directions across the chunks.
-    const size_t small_budget = 80 * 1024, big_budget = 156 * 1024;
-    if (row_bytes * (size_t)L.n_mics <= small_budget) {
-        p.mic_chunk = L.n_mics; p.n_chunks = 1; p.waves = 8; p.dpw = 1;
+    // One 1024-thread workgroup (16 waves) per CU owns the whole 160 KiB LDS:
+    //   [ mic rows of one frame (or one chunk of them) | per-wave power scratch: waves x pbw rows of 64*nc+1 floats ]
+    // When the frame's mic block does not fit beside the scratch, the mics are staged in chunks and every wave
+    // carries DPW directions' accumulators across the chunks.
+    const size_t lds_budget = 160 * 1024;
+    p.waves = 16;
+    p.srow = p.nc * kWave + 1;
+    p.pbw = p.nc <= 4 ? 4 : p.nc <= 8 ? 2 : 1;
+    const size_t scratch_bytes = (size_t)p.waves * p.pbw * p.srow * sizeof(float);
+    const size_t sig_budget = lds_budget - scratch_bytes - 16;
+    if (row_bytes * (size_t)L.n_mics <= sig_budget) {
+        p.mic_chunk = L.n_mics; p.n_chunks = 1; p.dpw = 1;
     } else {
-        int mc = (int)(big_budget / row_bytes);
+        int mc = (int)(sig_budget / row_bytes);
         if (mc < 1) return fail(3);
         if (mc >= 4) mc &= ~3;
         if (mc > L.n_mics) mc = L.n_mics;
         p.mic_chunk = mc; p.n_chunks = (L.n_mics + mc - 1) / mc;
-        p.waves = 16; p.dpw = p.n_chunks > 1 ? 4 : 1;
+        p.dpw = p.n_chunks > 1 ? 4 : 1;
     }
-    p.lds_bytes = row_bytes * (size_t)p.mic_chunk;
+    p.scratch_off = round_up(p.mic_chunk * p.row_stride, 4);
+    p.lds_bytes = (size_t)p.scratch_off * sizeof(float) + scratch_bytes;
 
     // Tile size: enough workgroups to fill the chip a few times over, but as many directions per staged block
     // as possible.  A tile is a whole number of wave groups.
