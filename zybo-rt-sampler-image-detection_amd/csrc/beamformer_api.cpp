@@ -260,8 +260,10 @@ bool describe(int algo, int slot, int n, bf::DasLaunch* L)
     return true;
 }
 
-bool plan_or_error(const bf::DasLaunch& L, bf::DasPlan* plan)
+bool plan_or_error(bf::DasLaunch& L, bf::DasPlan* plan)
 {
+    static const bool strided = [] { const char* e = getenv("BF_FORCE_STRIDED"); return e && e[0] == '1'; }();
+    L.force_strided = strided ? 1 : 0;   // A/B switch for tests and profiling: never use the quad layout
     const char* why = "";
     if (bf::plan_das(L, S().n_cus, plan, &why) != 0) { set_error("unsupported shape: %s", why); return false; }
     return true;

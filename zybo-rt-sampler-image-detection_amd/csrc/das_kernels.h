@@ -39,6 +39,7 @@ struct DasLaunch {
     int dir_begin, dir_end;  // shard of the direction grid handled by this launch
     int image_stride, image_origin;
     int frames;
+    int force_strided;       // tests/bench: 1 = never pick the quad layout
 };
 
 // Plan chosen on the host for a launch (exposed so tests can check LDS sizing without a GPU).
@@ -50,8 +51,9 @@ struct DasPlan {
     int n_chunks;
     int waves;       // waves per workgroup
     int scratch_off; // float offset of the per-wave power scratch in LDS
-    int srow;        // scratch row stride in floats (odd: 64*nc + 1)
+    int srow;        // scratch row stride in floats (64*nc + 4)
     int pbw;         // scratch rows (finished directions) per wave
+    int quad;        // 1: lane owns 4 consecutive samples (ds_read_b128 + DPP), 0: lane-strided samples (ds_read_b32)
     int dpw;         // directions a wave carries across mic chunks
     int tile_dirs;   // directions per workgroup
     int n_tiles;     // padded to a multiple of 8 (XCD affinity: tile % 8 == workgroup id % 8)

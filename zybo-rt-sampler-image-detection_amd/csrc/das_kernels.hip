@@ -172,6 +172,162 @@ __device__ __forceinline__ void accumulate(float (&acc)[NC], const float* lds, c
     }
 }
 
+// ---- "quad" layout for blocks of up to 256 samples (the reference's N_SAMPLES) ------------------------------
+// Lane l owns the four CONSECUTIVE samples 4l .. 4l+3, so one conflict-free ds_read_b128 per (direction, mic)
+// brings all 256 samples of a mic row into the wave: a quarter of the LDS cycles of the strided layout above.
+// A delay p = 4q + r shifts the row by q whole quads (folded into the 16-byte-aligned LDS address) and by r
+// samples inside the quad: those r leading values come from the previous lane's quad through DPP (wave_shr:1,
+// lane 0 receives 0 = the zero prefix), and r is wave-uniform, so the four register alignments are four
+// scalar-branch targets -- no per-lane select.  Mic order and operation order are unchanged.
+__device__ __forceinline__ float lane_prev(float x)
+{
+    // wave_shr:1 (0x138), all rows/banks, bound_ctrl: lane 0 reads 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xf, 0xf, true));
+}
+
+// One (direction, mic) step on a quad, as ONE inline-asm statement: a two-level scalar branch on r = p & 3
+// selects one of four straight-line bodies.  Written in asm because (a) the previous lane's values are consumed
+// through the DPP operand of the instruction that uses them (no v_mov), (b) the accumulators stay in the same
+// four VGPRs on every path (hipcc's structurizer otherwise turns the wave-uniform switch into "flow" blocks
+// with register copies), and (c) the branch is a plain s_cbranch_scc on an SGPR.
+// DPP control: wave_shr:1 = src0 comes from lane-1; bound_ctrl:1 = lane 0 reads 0 (the row's zero prefix).
+// The DPP sources are written by ds_read, not by a VALU instruction, so no VALU->DPP wait states are owed; a
+// v_mov_b32_dpp result is consumed by ordinary (non-DPP) reads, which need none either.
+#define BF_DPP " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+
+template <int ALGO>
+__device__ __forceinline__ void quad_one(float (&acc)[4], const float4 Q, int p, float h, int lane)
+{
+    int tmp;
+    if constexpr (ALGO == ALGO_PAD) {
+        // out[k] += s[k - p]:   acc[t] += W[4 - r + t],  W = [previous lane's quad | Q]
+        asm volatile(
+            "s_and_b32 %[t], %[p], 3\n\t"
+            "s_cmp_lt_u32 %[t], 2\n\t"
+            "s_cbranch_scc1 .Lbf_lo_%=\n\t"
+            "s_cmp_eq_u32 %[t], 2\n\t"
+            "s_cbranch_scc1 .Lbf_r2_%=\n\t"
+            /* r = 3 */
+            "v_add_f32_dpp %[a0], %[qy], %[a0]" BF_DPP
+            "v_add_f32_dpp %[a1], %[qz], %[a1]" BF_DPP
+            "v_add_f32_dpp %[a2], %[qw], %[a2]" BF_DPP
+            "v_add_f32 %[a3], %[a3], %[qx]\n\t"
+            "s_branch .Lbf_end_%=\n"
+            ".Lbf_r2_%=:\n\t"
+            "v_add_f32_dpp %[a0], %[qz], %[a0]" BF_DPP
+            "v_add_f32_dpp %[a1], %[qw], %[a1]" BF_DPP
+            "v_add_f32 %[a2], %[a2], %[qx]\n\t"
+            "v_add_f32 %[a3], %[a3], %[qy]\n\t"
+            "s_branch .Lbf_end_%=\n"
+            ".Lbf_lo_%=:\n\t"
+            "s_cmp_eq_u32 %[t], 0\n\t"
+            "s_cbranch_scc1 .Lbf_r0_%=\n\t"
+            /* r = 1 */
+            "v_add_f32_dpp %[a0], %[qw], %[a0]" BF_DPP
+            "v_add_f32 %[a1], %[a1], %[qx]\n\t"
+            "v_add_f32 %[a2], %[a2], %[qy]\n\t"
+            "v_add_f32 %[a3], %[a3], %[qz]\n\t"
+            "s_branch .Lbf_end_%=\n"
+            ".Lbf_r0_%=:\n\t"
+            "v_add_f32 %[a0], %[a0], %[qx]\n\t"
+            "v_add_f32 %[a1], %[a1], %[qy]\n\t"
+            "v_add_f32 %[a2], %[a2], %[qz]\n\t"
+            "v_add_f32 %[a3], %[a3], %[qw]\n"
+            ".Lbf_end_%=:"
+            : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [t] "=&s"(tmp)
+            : [p] "s"(p), [qx] "v"(Q.x), [qy] "v"(Q.y), [qz] "v"(Q.z), [qw] "v"(Q.w)
+            : "scc");
+    } else {
+        // out[k] += a + h * (b - a),  a = s[k - p - 1], b = s[k - p];  nothing for k <= p.
+        // With p = 4q + r and W = [previous lane's quad | Q]:  a_t = W[3 - r + t], b_t = W[4 - r + t], always inside W.
+        // With the zero prefix the only sample that would wrongly receive something is k == p (a = 0, b = s[0]):
+        // lane q, element r -- cleared by the v_and with `keep`.
+        // Per element, in the reference's order: d = b - a;  v = fma(h, d, a);  acc += v.
+        const int keep = (lane != (p >> 2)) ? -1 : 0;
+        float w0, w1, w2, w3, t0, t1, t2, t3;
+        asm volatile(
+            "s_and_b32 %[t], %[p], 3\n\t"
+            "s_cmp_lt_u32 %[t], 2\n\t"
+            "s_cbranch_scc1 .Lbf_lo_%=\n\t"
+            "s_cmp_eq_u32 %[t], 2\n\t"
+            "s_cbranch_scc1 .Lbf_r2_%=\n\t"
+            /* r = 3: w = [pQx, pQy, pQz, pQw, Qx] */
+            "v_mov_b32_dpp %[w0], %[qx]" BF_DPP
+            "v_mov_b32_dpp %[w1], %[qy]" BF_DPP
+            "v_mov_b32_dpp %[w2], %[qz]" BF_DPP
+            "v_mov_b32_dpp %[w3], %[qw]" BF_DPP
+            "v_sub_f32 %[t0], %[w1], %[w0]\n\tv_sub_f32 %[t1], %[w2], %[w1]\n\tv_sub_f32 %[t2], %[w3], %[w2]\n\tv_sub_f32 %[t3], %[qx], %[w3]\n\t"
+            "v_fma_f32 %[t0], %[h], %[t0], %[w0]\n\tv_fma_f32 %[t1], %[h], %[t1], %[w1]\n\tv_fma_f32 %[t2], %[h], %[t2], %[w2]\n\tv_fma_f32 %[t3], %[h], %[t3], %[w3]\n\t"
+            "v_and_b32 %[t3], %[t3], %[keep]\n\t"
+            "s_branch .Lbf_end_%=\n"
+            ".Lbf_r2_%=:\n\t"
+            /* r = 2: w = [pQy, pQz, pQw, Qx, Qy] */
+            "v_mov_b32_dpp %[w0], %[qy]" BF_DPP
+            "v_mov_b32_dpp %[w1], %[qz]" BF_DPP
+            "v_mov_b32_dpp %[w2], %[qw]" BF_DPP
+            "v_sub_f32 %[t0], %[w1], %[w0]\n\tv_sub_f32 %[t1], %[w2], %[w1]\n\tv_sub_f32 %[t2], %[qx], %[w2]\n\tv_sub_f32 %[t3], %[qy], %[qx]\n\t"
+            "v_fma_f32 %[t0], %[h], %[t0], %[w0]\n\tv_fma_f32 %[t1], %[h], %[t1], %[w1]\n\tv_fma_f32 %[t2], %[h], %[t2], %[w2]\n\tv_fma_f32 %[t3], %[h], %[t3], %[qx]\n\t"
+            "v_and_b32 %[t2], %[t2], %[keep]\n\t"
+            "s_branch .Lbf_end_%=\n"
+            ".Lbf_lo_%=:\n\t"
+            "s_cmp_eq_u32 %[t], 0\n\t"
+            "s_cbranch_scc1 .Lbf_r0_%=\n\t"
+            /* r = 1: w = [pQz, pQw, Qx, Qy, Qz] */
+            "v_mov_b32_dpp %[w0], %[qz]" BF_DPP
+            "v_mov_b32_dpp %[w1], %[qw]" BF_DPP
+            "v_sub_f32 %[t0], %[w1], %[w0]\n\tv_sub_f32 %[t1], %[qx], %[w1]\n\tv_sub_f32 %[t2], %[qy], %[qx]\n\tv_sub_f32 %[t3], %[qz], %[qy]\n\t"
+            "v_fma_f32 %[t0], %[h], %[t0], %[w0]\n\tv_fma_f32 %[t1], %[h], %[t1], %[w1]\n\tv_fma_f32 %[t2], %[h], %[t2], %[qx]\n\tv_fma_f32 %[t3], %[h], %[t3], %[qy]\n\t"
+            "v_and_b32 %[t1], %[t1], %[keep]\n\t"
+            "s_branch .Lbf_end_%=\n"
+            ".Lbf_r0_%=:\n\t"
+            /* r = 0: w = [pQw, Qx, Qy, Qz, Qw] */
+            "v_mov_b32_dpp %[w0], %[qw]" BF_DPP
+            "v_sub_f32 %[t0], %[qx], %[w0]\n\tv_sub_f32 %[t1], %[qy], %[qx]\n\tv_sub_f32 %[t2], %[qz], %[qy]\n\tv_sub_f32 %[t3], %[qw], %[qz]\n\t"
+            "v_fma_f32 %[t0], %[h], %[t0], %[w0]\n\tv_fma_f32 %[t1], %[h], %[t1], %[qx]\n\tv_fma_f32 %[t2], %[h], %[t2], %[qy]\n\tv_fma_f32 %[t3], %[h], %[t3], %[qz]\n\t"
+            "v_and_b32 %[t0], %[t0], %[keep]\n"
+            ".Lbf_end_%=:\n\t"
+            "v_add_f32 %[a0], %[a0], %[t0]\n\tv_add_f32 %[a1], %[a1], %[t1]\n\tv_add_f32 %[a2], %[a2], %[t2]\n\tv_add_f32 %[a3], %[a3], %[t3]"
+            : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [t] "=&s"(tmp),
+              [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+            : [p] "s"(p), [h] "s"(h), [keep] "v"(keep), [qx] "v"(Q.x), [qy] "v"(Q.y), [qz] "v"(Q.z), [qw] "v"(Q.w)
+            : "scc");
+    }
+}
+
+template <int ALGO>
+__device__ __forceinline__ void accumulate_quad(float (&acc)[4], const float* lds, const KArgs& a, const int32_t* __restrict__ whole,
+                                                const float* __restrict__ frac, size_t row_base, int m0, int mc, int lane)
+{
+    static_assert(ALGO == ALGO_PAD || ALGO == ALGO_LERP, "quad layout: pad and lerp");
+    const size_t row = row_base + m0;
+    const int rs = a.row_stride;
+    const int32_t* __restrict__ wrow = whole + row;
+    const float* __restrict__ hrow = frac + row;
+    constexpr int kBias = 0;
+    const float* base = lds + a.lead + 4 * lane;
+    int ms = 0;
+    for (; ms + 4 <= mc; ms += 4) {
+        const int p0 = wrow[ms] + kBias, p1 = wrow[ms + 1] + kBias, p2 = wrow[ms + 2] + kBias, p3 = wrow[ms + 3] + kBias;
+        float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
+        if constexpr (ALGO == ALGO_LERP) { h0 = hrow[ms]; h1 = hrow[ms + 1]; h2 = hrow[ms + 2]; h3 = hrow[ms + 3]; }
+        const float4 Q0 = *reinterpret_cast<const float4*>(base + (ms + 0) * rs - (p0 & ~3));
+        const float4 Q1 = *reinterpret_cast<const float4*>(base + (ms + 1) * rs - (p1 & ~3));
+        const float4 Q2 = *reinterpret_cast<const float4*>(base + (ms + 2) * rs - (p2 & ~3));
+        const float4 Q3 = *reinterpret_cast<const float4*>(base + (ms + 3) * rs - (p3 & ~3));
+        quad_one<ALGO>(acc, Q0, p0, h0, lane);
+        quad_one<ALGO>(acc, Q1, p1, h1, lane);
+        quad_one<ALGO>(acc, Q2, p2, h2, lane);
+        quad_one<ALGO>(acc, Q3, p3, h3, lane);
+    }
+    for (; ms < mc; ++ms) {
+        const int p = wrow[ms] + kBias;
+        float h = 0.f;
+        if constexpr (ALGO == ALGO_LERP) h = hrow[ms];
+        const float4 Q = *reinterpret_cast<const float4*>(base + ms * rs - (p & ~3));
+        quad_one<ALGO>(acc, Q, p, h, lane);
+    }
+}
+
 // ---- mean power, in the reference's summation order ------------------------------------------------------
 // The reference finishes a direction with (pad_and_sum.c:122-131)
 //     for k: out[k] /= n; sum += out[k]^2          (gcc: vdivps, vmulps, then one vaddss per k, in k order)
@@ -179,31 +335,49 @@ __device__ __forceinline__ void accumulate(float (&acc)[NC], const float* lds, c
 // A float32 sum of N squares taken in another order differs from that by up to ~N*2^-24 relative (2e-5 observed
 // at N = 1024), which is more than the 1e-5 parity bar.  So the squares are summed in k order here too:
 // every wave parks the squares of `pbw` finished directions as rows of a private LDS scratch, then lanes
-// 0..pbw-1 each walk one row front to back.  Row stride is odd, so the lanes' reads never share a bank.
-template <int NC>
+// 0..pbw-1 each walk one row front to back (ds_read_b128, four ordered adds per read).
+template <int NC, bool QUAD>
 __device__ __forceinline__ void park_squares(const float (&acc)[NC], float* scratch_row, const KArgs& a, int d, int lane)
 {
+    float sq[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         // out[k] /= (float)n: for a power-of-two n the reciprocal multiply is exact; otherwise a true division
         const float o = a.n_is_pow2 ? acc[c] * a.inv_n : acc[c] / (float)a.n_mics;
-        if (lane + c * kWave < a.n_samples) scratch_row[lane + c * kWave] = o * o;
+        sq[c] = o * o;
     }
-    if (lane == 0) scratch_row[a.srow - 1] = __int_as_float(d);   // the pad column carries the direction id
+    if constexpr (QUAD) {
+        // lane l owns samples 4l..4l+3: one aligned 16-byte store (entries past N are never summed)
+        *reinterpret_cast<float4*>(scratch_row + 4 * lane) = make_float4(sq[0], sq[1], sq[2], sq[3]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) scratch_row[lane + c * kWave] = sq[c];
+    }
+    if (lane == 0) scratch_row[a.srow - 4] = __int_as_float(d);   // the pad column carries the direction id
 }
 
+// Rows are 16-byte aligned and 4 (mod 64) dwords apart, so up to 16 lanes can each stream their own row with
+// ds_read_b128 without sharing a bank; the additions stay strictly in k order.
 __device__ __forceinline__ void flush_powers(const float* scratch, int filled, float* __restrict__ img, const KArgs& a, int lane)
 {
     if (lane < filled) {
         const float* row = scratch + lane * a.srow;
+        const float4* row4 = reinterpret_cast<const float4*>(row);
+        const int n = a.n_samples;
         float sum = 0.0f;
-        for (int k = 0; k < a.n_samples; ++k) sum += row[k];
-        const int d = __float_as_int(row[a.srow - 1]);
-        img[d - a.image_origin] = sum / (float)a.n_samples;
+        int k = 0;
+#pragma unroll 4
+        for (; k + 4 <= n; k += 4) {
+            const float4 v = row4[k >> 2];
+            sum += v.x; sum += v.y; sum += v.z; sum += v.w;
+        }
+        for (; k < n; ++k) sum += row[k];
+        const int d = __float_as_int(row[a.srow - 4]);
+        img[d - a.image_origin] = sum / (float)n;
     }
 }
 
-template <int ALGO, int NC, int DPW>
+template <int ALGO, int NC, int DPW, bool QUAD>
 __global__ void __launch_bounds__(1024) das_mimo_kernel(BF_TABLE_PARAMS, KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -248,14 +422,17 @@ __global__ void __launch_bounds__(1024) das_mimo_kernel(BF_TABLE_PARAMS, KArgs a
 #pragma unroll
             for (int j = 0; j < DPW; ++j) {
                 const int d = g0 + j * nwaves + wave;  // wave-uniform
-                if (d < tile_end) accumulate<ALGO, NC>(acc[j], lds, a, whole, frac, taps, (size_t)d * a.n_mics, m0, mc, lane);
+                if (d < tile_end) {
+                    if constexpr (QUAD) accumulate_quad<ALGO>(acc[j], lds, a, whole, frac, (size_t)d * a.n_mics, m0, mc, lane);
+                    else accumulate<ALGO, NC>(acc[j], lds, a, whole, frac, taps, (size_t)d * a.n_mics, m0, mc, lane);
+                }
             }
         }
 #pragma unroll
         for (int j = 0; j < DPW; ++j) {
             const int d = g0 + j * nwaves + wave;
             if (d < tile_end) {
-                park_squares<NC>(acc[j], scratch + filled * a.srow, a, d, lane);
+                park_squares<NC, QUAD>(acc[j], scratch + filled * a.srow, a, d, lane);
                 if (++filled == a.pbw) { flush_powers(scratch, filled, img, a, lane); filled = 0; }
             }
         }
@@ -304,10 +481,18 @@ hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, in
         hipLaunchKernelGGL(kernel, grid, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole, L.tab.frac, L.tab.taps, a);
         return hipGetLastError();
     };
+    if constexpr (NC == 4 && (ALGO == ALGO_PAD || ALGO == ALGO_LERP)) {
+        if (plan.quad) {
+            switch (plan.dpw) {
+                case 1: return go(das_mimo_kernel<ALGO, 4, 1, true>);
+                case 4: return go(das_mimo_kernel<ALGO, 4, 4, true>);
+                default: return hipErrorInvalidValue;
+            }
+        }
+    }
     switch (plan.dpw) {
-        case 1: return go(das_mimo_kernel<ALGO, NC, 1>);
-        case 2: return go(das_mimo_kernel<ALGO, NC, 2>);
-        case 4: return go(das_mimo_kernel<ALGO, NC, 4>);
+        case 1: return go(das_mimo_kernel<ALGO, NC, 1, false>);
+        case 4: return go(das_mimo_kernel<ALGO, NC, 4, false>);
         default: return hipErrorInvalidValue;
     }
 }
@@ -385,12 +570,12 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
     const size_t row_bytes = (size_t)p.row_stride * sizeof(float);
 
     // One 1024-thread workgroup (16 waves) per CU owns the whole 160 KiB LDS:
-    //   [ mic rows of one frame (or one chunk of them) | per-wave power scratch: waves x pbw rows of 64*nc+1 floats ]
+    //   [ mic rows of one frame (or one chunk of them) | per-wave power scratch: waves x pbw rows of 64*nc+4 floats ]
     // When the frame's mic block does not fit beside the scratch, the mics are staged in chunks and every wave
     // carries DPW directions' accumulators across the chunks.
     const size_t lds_budget = 160 * 1024;
     p.waves = 16;
-    p.srow = p.nc * kWave + 1;
+    p.srow = p.nc * kWave + 4;   // +4: keeps rows 16-byte aligned and 4 banks apart; column nc*64 holds the direction id
     p.pbw = p.nc <= 4 ? 4 : p.nc <= 8 ? 2 : 1;
     const size_t scratch_bytes = (size_t)p.waves * p.pbw * p.srow * sizeof(float);
     const size_t sig_budget = lds_budget - scratch_bytes - 16;
@@ -404,6 +589,7 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
         p.mic_chunk = mc; p.n_chunks = (L.n_mics + mc - 1) / mc;
         p.dpw = p.n_chunks > 1 ? 4 : 1;
     }
+    p.quad = (p.nc == 4 && (L.algo == ALGO_PAD || L.algo == ALGO_LERP) && !L.force_strided) ? 1 : 0;
     p.scratch_off = round_up(p.mic_chunk * p.row_stride, 4);
     p.lds_bytes = (size_t)p.scratch_off * sizeof(float) + scratch_bytes;
 
