@@ -132,13 +132,13 @@ __global__ void __launch_bounds__(1024) probe(const int* __restrict__ tab, float
 }
 
 template <int MODE, int UNROLL>
-int run(const char* name, const int* d_tab, float* d_out, int waves, int rmode)
+int run(const char* name, const int* d_tab, float* d_out, int waves, int rmode, int lds_kb = 80)
 {
     const int iters = 400, blocks = 256 * 2, rs = 256 + 48;
     const size_t lds = 64 * 1024 + 4096;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(probe<MODE, UNROLL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024)));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(probe<MODE, UNROLL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const size_t shmem = waves == 16 ? 80 * 1024 : 72 * 1024;   // 16 waves: one WG per CU... (two 80 KB WGs fit a CU, so use 2 blocks/CU when waves == 8)
+    const size_t shmem = (size_t)lds_kb * 1024;   // 16 waves: one WG per CU... (two 80 KB WGs fit a CU, so use 2 blocks/CU when waves == 8)
     (void)lds;
     for (int rep = 0; rep < 2; ++rep) {
         CK(hipEventRecord(e0));
@@ -151,7 +151,7 @@ int run(const char* name, const int* d_tab, float* d_out, int waves, int rmode)
     std::vector<float> ho(1024); (void)hipMemcpy(ho.data(), d_out, 1024 * sizeof(float), hipMemcpyDeviceToHost);
     double chk = 0; for (float v : ho) chk += v;
     printf("[chk %.6e] ", chk);
-    printf("%-28s waves/WG %2d tablemode %d: %.3f ms  %.2f cycles per (d,m) per CU  -> %.1f MAC/clk/CU\n", name, waves, rmode, ms, cyc_per_dm_cu, 256.0 / cyc_per_dm_cu);
+    printf("%-28s lds %3d KB waves/WG %2d tablemode %d: %.3f ms  %.2f cycles per (d,m) per CU  -> %.1f MAC/clk/CU\n", name, lds_kb, waves, rmode, ms, cyc_per_dm_cu, 256.0 / cyc_per_dm_cu);
     return 0;
 }
 
@@ -166,6 +166,10 @@ int main()
         for (int i = 0; i < entries; ++i) { s = s * 1664525u + 1013904223u; int p = (s >> 16) % 44; h[i] = rmode == 0 ? (p & ~3) : p; }
         CK(hipMemcpy(d_tab, h.data(), entries * sizeof(int), hipMemcpyHostToDevice));
         for (int waves : {16}) {
+            if (run<0, 4>("b32x4 unroll4", d_tab, d_out, waves, rmode, 136)) return 1;
+            if (run<0, 8>("b32x4 unroll8", d_tab, d_out, waves, rmode, 136)) return 1;
+            if (run<1, 8>("b128 unroll8", d_tab, d_out, waves, rmode, 136)) return 1;
+            if (run<3, 8>("b128+branch unroll8", d_tab, d_out, waves, rmode, 136)) return 1;
             if (run<0, 4>("b32x4 unroll4", d_tab, d_out, waves, rmode)) return 1;
             if (run<0, 8>("b32x4 unroll8", d_tab, d_out, waves, rmode)) return 1;
             if (run<1, 4>("b128 unroll4", d_tab, d_out, waves, rmode)) return 1;

@@ -262,8 +262,10 @@ bool describe(int algo, int slot, int n, bf::DasLaunch* L)
 
 bool plan_or_error(bf::DasLaunch& L, bf::DasPlan* plan)
 {
-    static const bool strided = [] { const char* e = getenv("BF_FORCE_STRIDED"); return e && e[0] == '1'; }();
-    L.force_strided = strided ? 1 : 0;   // A/B switch for tests and profiling: never use the quad layout
+    static const int layout = [] { const char* e = getenv("BF_LAYOUT"); return e ? atoi(e) : -1; }();
+    L.force_layout = layout;             // A/B switch for tests and profiling (see DasPlan::layout)
+    static const int debug = [] { const char* e = getenv("BF_DEBUG"); return e ? atoi(e) : 0; }();
+    L.debug = debug;
     const char* why = "";
     if (bf::plan_das(L, S().n_cus, plan, &why) != 0) { set_error("unsupported shape: %s", why); return false; }
     return true;
@@ -764,6 +766,7 @@ int bf_plan_das(int algo, int n, int frames, int dir_begin, int dir_end, int max
     sizes_from_env_once();
     bf::DasLaunch L{};
     L.algo = algo; L.n_mics = n; L.m_total = n; L.n_samples = s.sz.n_samples; L.n_taps = s.sz.n_taps; L.n_dirs = s.sz.dirs();
+    L.force_layout = -1;
     L.dir_begin = dir_begin; L.dir_end = dir_end; L.frames = frames; L.tab.max_whole = max_whole;
     bf::DasPlan p{};
     const char* why = "";

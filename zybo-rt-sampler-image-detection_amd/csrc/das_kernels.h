@@ -39,7 +39,8 @@ struct DasLaunch {
     int dir_begin, dir_end;  // shard of the direction grid handled by this launch
     int image_stride, image_origin;
     int frames;
-    int force_strided;       // tests/bench: 1 = never pick the quad layout
+    int force_layout;        // tests/bench ($BF_LAYOUT): -1 = planner's choice, else 0 / 1 / 2 for pad and lerp at N <= 256
+    int debug;               // profiling switches ($BF_DEBUG), 0 in production
 };
 
 // Plan chosen on the host for a launch (exposed so tests can check LDS sizing without a GPU).
@@ -54,6 +55,7 @@ struct DasPlan {
     int srow;        // scratch row stride in floats (64*nc + 4)
     int pbw;         // scratch rows (finished directions) per wave
     int quad;        // 1: lane owns 4 consecutive samples (ds_read_b128 + DPP), 0: lane-strided samples (ds_read_b32)
+    int layout;      // 0 strided, 1 quad + DPP, 2 shifted copies (pad / lerp, N <= 256)
     int dpw;         // directions a wave carries across mic chunks
     int tile_dirs;   // directions per workgroup
     int n_tiles;     // padded to a multiple of 8 (XCD affinity: tile % 8 == workgroup id % 8)

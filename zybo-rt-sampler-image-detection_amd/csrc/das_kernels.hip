@@ -36,6 +36,7 @@ struct KArgs {
     int scratch_off, srow, pbw;           // per-wave power scratch: float offset in LDS, row stride, rows per wave
     int n_is_pow2;
     float inv_n;
+    int debug;   // profiling only (BF_DEBUG): bit 0 = skip the ordered power sum (wrong images)
 };
 
 // The read-only tables are separate `const __restrict__` kernel parameters on purpose: only then can the
@@ -73,43 +74,98 @@ __device__ __forceinline__ void stage_chunk(float* lds, const KArgs& a, const in
     }
 }
 
+// First 64-entry block of a table row, requested one work item ahead (pad / lerp): lane m holds entry m.
+struct RowHead {
+    int p = 0;
+    float h = 0.0f;
+    bool valid = false;   // wave-uniform
+};
+
+template <int ALGO>
+__device__ __forceinline__ RowHead request_row_head(const int32_t* __restrict__ whole, const float* __restrict__ frac, size_t row, int mc, int lane)
+{
+    RowHead r;
+    if constexpr (ALGO == ALGO_PAD || ALGO == ALGO_LERP) {
+        r.p = (lane < mc) ? whole[row + lane] : 0;
+        if constexpr (ALGO == ALGO_LERP) r.h = (lane < mc) ? frac[row + lane] : 0.0f;
+        r.valid = true;
+    }
+    return r;
+}
+
 // Accumulate mics [m0, m0+mc) of the table row starting at flat entry `row_base` (= d*M for direction d)
 // into acc[NC] (lane l holds samples l + 64 c).
 template <int ALGO, int NC>
 __device__ __forceinline__ void accumulate(float (&acc)[NC], const float* lds, const KArgs& a, const int32_t* __restrict__ whole,
                                            const float* __restrict__ frac, const float* __restrict__ taps, size_t row_base, int m0,
-                                           int mc, int lane)
+                                           int mc, int lane, const RowHead head = RowHead())
 {
     const size_t row = row_base + m0;
     const int rs = a.row_stride;
 
-    if constexpr (ALGO == ALGO_PAD) {
-        // pad_and_sum.c:41-47,54-70   out[p + i] += s[i]
-        const int32_t* __restrict__ wrow = whole + row;
-#pragma unroll 4
-        for (int ms = 0; ms < mc; ++ms) {
-            const int p = wrow[ms];
-            const float* r = lds + ms * rs + (a.lead - p) + lane;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) acc[c] += r[c * kWave];
-        }
-    } else if constexpr (ALGO == ALGO_LERP) {
-        // lerp_and_sum.c:50-56,67-92  out[p + i + 1] += s[i] + h * (s[i+1] - s[i]),  0 <= i < N - p - 1
+    // pad / lerp: the table row of a direction is fetched 64 mics at a time with ONE coalesced vector load (lane m
+    // holds entry m; the next block is requested before the current one is consumed) and the wave-uniform entry of
+    // each mic is then read out of that register with v_readlane.  Scalar loads would need no VALU slot, but
+    // every new row misses the scalar cache and s_load shares the LDS wait counter, so their latency sat fully
+    // exposed in front of every group of LDS reads (measured: 14 instead of 9 cycles per (direction, mic) per CU).
+    if constexpr (ALGO == ALGO_PAD || ALGO == ALGO_LERP) {
         const int32_t* __restrict__ wrow = whole + row;
         const float* __restrict__ hrow = frac + row;
-#pragma unroll 2
-        for (int ms = 0; ms < mc; ++ms) {
-            const int p = wrow[ms];
-            const float h = hrow[ms];
-            const float* r = lds + ms * rs + (a.lead - p - 1) + lane;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const float s0 = r[c * kWave];
-                const float s1 = r[c * kWave + 1];
-                float v = __fmaf_rn(h, s1 - s0, s0);      // gcc contracts s0 + h*(s1-s0) into one fma
-                if (c * kWave <= p) v = (lane + c * kWave > p) ? v : 0.0f;   // i >= 0 only (wave-uniform guard)
-                acc[c] += v;
+        int vp = head.p;
+        float vh = head.h;
+        if (!head.valid) {
+            vp = (lane < mc) ? wrow[lane] : 0;
+            if constexpr (ALGO == ALGO_LERP) vh = (lane < mc) ? hrow[lane] : 0.0f;
+        }
+        for (int b0 = 0; b0 < mc; b0 += kWave) {
+            const int bn = min(kWave, mc - b0);
+            int vp_next = 0;
+            float vh_next = 0.0f;
+            if (b0 + kWave < mc) {   // wave-uniform
+                vp_next = (b0 + kWave + lane < mc) ? wrow[b0 + kWave + lane] : 0;
+                if constexpr (ALGO == ALGO_LERP) vh_next = (b0 + kWave + lane < mc) ? hrow[b0 + kWave + lane] : 0.0f;
             }
+            // (v_readlane is a convergent operation: the compiler will not unroll a runtime-trip loop around it, so the
+            //  blocks of 8 / 4 mics are spelled out and a scalar remainder loop follows)
+            auto pad_one = [&](int u) {
+                // pad_and_sum.c:41-47,54-70   out[p + i] += s[i]
+                const int p = __builtin_amdgcn_readlane(vp, u);
+                const float* r = lds + (b0 + u) * rs + (a.lead - p) + lane;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c] += r[c * kWave];
+            };
+            auto lerp_one = [&](int u) {
+                // lerp_and_sum.c:50-56,67-92  out[p + i + 1] += s[i] + h * (s[i+1] - s[i]),  0 <= i < N - p - 1
+                const int p = __builtin_amdgcn_readlane(vp, u);
+                const float h = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vh), u));
+                const float* r = lds + (b0 + u) * rs + (a.lead - p - 1) + lane;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float s0 = r[c * kWave];
+                    const float s1 = r[c * kWave + 1];
+                    float v = __fmaf_rn(h, s1 - s0, s0);      // gcc contracts s0 + h*(s1-s0) into one fma
+                    if (c * kWave <= p) v = (lane + c * kWave > p) ? v : 0.0f;   // i >= 0 only (wave-uniform guard)
+                    acc[c] += v;
+                }
+            };
+            int u = 0;
+            if constexpr (ALGO == ALGO_PAD) {
+                constexpr int kU = NC <= 4 ? 8 : 4;
+                for (; u + kU <= bn; u += kU) {
+#pragma unroll
+                    for (int i = 0; i < kU; ++i) pad_one(u + i);
+                }
+                for (; u < bn; ++u) pad_one(u);
+            } else {
+                constexpr int kU = NC <= 4 ? 4 : 2;
+                for (; u + kU <= bn; u += kU) {
+#pragma unroll
+                    for (int i = 0; i < kU; ++i) lerp_one(u + i);
+                }
+                for (; u < bn; ++u) lerp_one(u);
+            }
+            vp = vp_next;
+            vh = vh_next;
         }
     } else if constexpr (ALGO == ALGO_HYBRID) {
         // hybrid_convolve_and_sum.c:51-64  out[p + i + 1] += h[t] * padded[i + t], t = 0..T-1 in order
@@ -296,35 +352,54 @@ __device__ __forceinline__ void quad_one(float (&acc)[4], const float4 Q, int p,
 
 template <int ALGO>
 __device__ __forceinline__ void accumulate_quad(float (&acc)[4], const float* lds, const KArgs& a, const int32_t* __restrict__ whole,
-                                                const float* __restrict__ frac, size_t row_base, int m0, int mc, int lane)
+                                                const float* __restrict__ frac, size_t row_base, int m0, int mc, int lane,
+                                                const RowHead head = RowHead())
 {
     static_assert(ALGO == ALGO_PAD || ALGO == ALGO_LERP, "quad layout: pad and lerp");
     const size_t row = row_base + m0;
     const int rs = a.row_stride;
     const int32_t* __restrict__ wrow = whole + row;
     const float* __restrict__ hrow = frac + row;
-    constexpr int kBias = 0;
     const float* base = lds + a.lead + 4 * lane;
-    int ms = 0;
-    for (; ms + 4 <= mc; ms += 4) {
-        const int p0 = wrow[ms] + kBias, p1 = wrow[ms + 1] + kBias, p2 = wrow[ms + 2] + kBias, p3 = wrow[ms + 3] + kBias;
-        float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
-        if constexpr (ALGO == ALGO_LERP) { h0 = hrow[ms]; h1 = hrow[ms + 1]; h2 = hrow[ms + 2]; h3 = hrow[ms + 3]; }
-        const float4 Q0 = *reinterpret_cast<const float4*>(base + (ms + 0) * rs - (p0 & ~3));
-        const float4 Q1 = *reinterpret_cast<const float4*>(base + (ms + 1) * rs - (p1 & ~3));
-        const float4 Q2 = *reinterpret_cast<const float4*>(base + (ms + 2) * rs - (p2 & ~3));
-        const float4 Q3 = *reinterpret_cast<const float4*>(base + (ms + 3) * rs - (p3 & ~3));
-        quad_one<ALGO>(acc, Q0, p0, h0, lane);
-        quad_one<ALGO>(acc, Q1, p1, h1, lane);
-        quad_one<ALGO>(acc, Q2, p2, h2, lane);
-        quad_one<ALGO>(acc, Q3, p3, h3, lane);
+    // table rows: one coalesced vector load per 64 mics, entries scalarised with v_readlane (see accumulate())
+    int vp = head.p;
+    float vh = head.h;
+    if (!head.valid) {
+        vp = (lane < mc) ? wrow[lane] : 0;
+        if constexpr (ALGO == ALGO_LERP) vh = (lane < mc) ? hrow[lane] : 0.0f;
     }
-    for (; ms < mc; ++ms) {
-        const int p = wrow[ms] + kBias;
-        float h = 0.f;
-        if constexpr (ALGO == ALGO_LERP) h = hrow[ms];
-        const float4 Q = *reinterpret_cast<const float4*>(base + ms * rs - (p & ~3));
-        quad_one<ALGO>(acc, Q, p, h, lane);
+    for (int b0 = 0; b0 < mc; b0 += kWave) {
+        const int bn = min(kWave, mc - b0);
+        int vp_next = 0;
+        float vh_next = 0.0f;
+        if (b0 + kWave < mc) {
+            vp_next = (b0 + kWave + lane < mc) ? wrow[b0 + kWave + lane] : 0;
+            if constexpr (ALGO == ALGO_LERP) vh_next = (b0 + kWave + lane < mc) ? hrow[b0 + kWave + lane] : 0.0f;
+        }
+        int u = 0;
+        for (; u + 4 <= bn; u += 4) {
+            int p[4];
+            float h[4];
+            float4 Q[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                p[i] = __builtin_amdgcn_readlane(vp, u + i);
+                h[i] = 0.f;
+                if constexpr (ALGO == ALGO_LERP) h[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vh), u + i));
+                Q[i] = *reinterpret_cast<const float4*>(base + (b0 + u + i) * rs - (p[i] & ~3));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) quad_one<ALGO>(acc, Q[i], p[i], h[i], lane);
+        }
+        for (; u < bn; ++u) {
+            const int p = __builtin_amdgcn_readlane(vp, u);
+            float h = 0.f;
+            if constexpr (ALGO == ALGO_LERP) h = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vh), u));
+            const float4 Q = *reinterpret_cast<const float4*>(base + (b0 + u) * rs - (p & ~3));
+            quad_one<ALGO>(acc, Q, p, h, lane);
+        }
+        vp = vp_next;
+        vh = vh_next;
     }
 }
 
@@ -404,6 +479,13 @@ __global__ void __launch_bounds__(1024) das_mimo_kernel(BF_TABLE_PARAMS, KArgs a
     float* scratch = lds + a.scratch_off + wave * (a.pbw * a.srow);
     int filled = 0;   // wave-uniform
 
+    // Work items of this wave, in order: for g0 / for chunk / for j.  The table-row head of item i+1 is requested
+    // (vector load, its own wait counter) before item i is computed, so its HBM/L2 latency hides behind ~64 mics of work.
+    auto item_dir = [&](int g0_, int j_) { return g0_ + j_ * nwaves + wave; };
+    RowHead head;
+    if (item_dir(tile_begin, 0) < tile_end)
+        head = request_row_head<ALGO>(whole, frac, (size_t)item_dir(tile_begin, 0) * a.n_mics, min(a.mic_chunk, a.n_mics), lane);
+
     for (int g0 = tile_begin; g0 < tile_end; g0 += group) {
         float acc[DPW][NC];
 #pragma unroll
@@ -422,9 +504,19 @@ __global__ void __launch_bounds__(1024) das_mimo_kernel(BF_TABLE_PARAMS, KArgs a
 #pragma unroll
             for (int j = 0; j < DPW; ++j) {
                 const int d = g0 + j * nwaves + wave;  // wave-uniform
+                // successor of (g0, ch, j)
+                int ng0 = g0, nch = ch, nj = j + 1;
+                if (nj == DPW) { nj = 0; nch = ch + 1; if (nch == a.n_chunks) { nch = 0; ng0 = g0 + group; } }
+                const int nd = item_dir(ng0, nj);
+                const RowHead cur = head;
+                head = RowHead();
+                if (nd < tile_end) {
+                    const int nm0 = nch * a.mic_chunk;
+                    head = request_row_head<ALGO>(whole, frac, (size_t)nd * a.n_mics + nm0, min(a.mic_chunk, a.n_mics - nm0), lane);
+                }
                 if (d < tile_end) {
-                    if constexpr (QUAD) accumulate_quad<ALGO>(acc[j], lds, a, whole, frac, (size_t)d * a.n_mics, m0, mc, lane);
-                    else accumulate<ALGO, NC>(acc[j], lds, a, whole, frac, taps, (size_t)d * a.n_mics, m0, mc, lane);
+                    if constexpr (QUAD) accumulate_quad<ALGO>(acc[j], lds, a, whole, frac, (size_t)d * a.n_mics, m0, mc, lane, cur);
+                    else accumulate<ALGO, NC>(acc[j], lds, a, whole, frac, taps, (size_t)d * a.n_mics, m0, mc, lane, cur);
                 }
             }
         }
@@ -432,6 +524,13 @@ __global__ void __launch_bounds__(1024) das_mimo_kernel(BF_TABLE_PARAMS, KArgs a
         for (int j = 0; j < DPW; ++j) {
             const int d = g0 + j * nwaves + wave;
             if (d < tile_end) {
+                if (a.debug & 1) {   // profiling only
+                    float t = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) t += acc[j][c];
+                    if (lane == 0) img[d - a.image_origin] = t;
+                    continue;
+                }
                 park_squares<NC, QUAD>(acc[j], scratch + filled * a.srow, a, d, lane);
                 if (++filled == a.pbw) { flush_powers(scratch, filled, img, a, lane); filled = 0; }
             }
@@ -469,6 +568,214 @@ __global__ void __launch_bounds__(64) das_miso_kernel(BF_TABLE_PARAMS, const flo
         if (lane + c * kWave < a.n_samples) miso_out[lane + c * kWave] = acc[c];
 }
 
+// ==================================================================================================
+// "Shifted-copies" layout: pad and lerp for blocks of up to 256 samples (the reference's N_SAMPLES).
+//
+// Profiling the kernels above showed the loop is bound by instructions issued per (direction, mic) -- ~16 for
+// the strided layout (two LDS reads, address arithmetic, waits) -- not by LDS bytes.  This layout spends LDS
+// capacity to cut that to ~8 (pad) / ~15 (lerp):
+//   * every staged mic row is kept in FOUR copies shifted by 0..3 samples, so a delay p = 4q + r becomes one
+//     16-byte-ALIGNED ds_read_b128 from copy r at quad offset -q: no sub-quad alignment work, no branches;
+//   * lane l owns the four consecutive samples 4l..4l+3 (one read = all 256 samples of the row);
+//   * for lerp the staged rows also carry D[i] = s[i+1] - s[i] (rounded exactly as the reference's subtraction,
+//     D[-1] = 0), so a sample is fma(h, D[i], s[i]) -- the reference's own two roundings -- and the i < 0 guard
+//     falls out of the zero prefix;
+//   * the copies of a whole frame no longer fit in LDS, so the mics are staged in chunks of 16 (pad) / 8 (lerp)
+//     and every wave carries 4 directions' accumulators across the chunks; the next chunk's samples are already
+//     in registers (global loads issued a chunk ahead) when the buffer is rewritten;
+//   * the chunk buffer (<= 80 KiB, two workgroups per CU) doubles as the scratch for the k-ordered power sum.
+// Mic order and operation order are unchanged, so the maps stay bit-identical to the CPU reference.
+namespace copies {
+
+constexpr int kDpw = 4;          // directions per wave
+constexpr int kWaves = 16;       // waves per workgroup
+constexpr int kGroup = kDpw * kWaves;
+constexpr int kParkStride = 260; // floats per parked row (256 squares, direction id at [256], 16-byte aligned rows)
+
+__device__ __forceinline__ float dpp_prev(float x)   // lane-1's value, 0 in lane 0
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_next(float x)   // lane+1's value, 0 in lane 63
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130, 0xf, 0xf, true));
+}
+
+// Write the four shifted copies of one quad-per-lane row: copy c holds s shifted right by c samples, i.e. its
+// aligned quad i is (s[4i-c], ..., s[4i-c+3]); the leading values come from the previous lane.
+__device__ __forceinline__ void write_copies(float* row0, int rs, int lead, int lane, float4 v)
+{
+    const float py = dpp_prev(v.y), pz = dpp_prev(v.z), pw = dpp_prev(v.w);
+    float4* q0 = reinterpret_cast<float4*>(row0 + 0 * rs + lead) + lane;
+    float4* q1 = reinterpret_cast<float4*>(row0 + 1 * rs + lead) + lane;
+    float4* q2 = reinterpret_cast<float4*>(row0 + 2 * rs + lead) + lane;
+    float4* q3 = reinterpret_cast<float4*>(row0 + 3 * rs + lead) + lane;
+    *q0 = v;
+    *q1 = make_float4(pw, v.x, v.y, v.z);
+    *q2 = make_float4(pz, pw, v.x, v.y);
+    *q3 = make_float4(py, pz, pw, v.x);
+    if (lane < (lead >> 2)) {   // the zero prefix (also wiped by the parked rows of the previous group)
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) reinterpret_cast<float4*>(row0 + c * rs)[lane] = z;
+    }
+}
+
+template <int ALGO>
+__global__ void __launch_bounds__(1024) das_copies_kernel(BF_TABLE_PARAMS, KArgs a)
+{
+    static_assert(ALGO == ALGO_PAD || ALGO == ALGO_LERP, "shifted-copies layout: pad and lerp");
+    constexpr int A = (ALGO == ALGO_LERP) ? 2 : 1;   // arrays per mic: s (and D)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tile = (int)(blockIdx.x % (unsigned)a.n_tiles);
+    const int frame = (int)(blockIdx.x / (unsigned)a.n_tiles);
+    const int tile_begin = a.dir_begin + tile * a.tile_dirs;
+    if (tile_begin >= a.dir_end) return;
+    const int tile_end = min(tile_begin + a.tile_dirs, a.dir_end);
+
+    const int rs = a.row_stride, lead = a.lead, mc = a.mic_chunk, M = a.n_mics, N = a.n_samples;
+    const float* __restrict__ frame_sig = signals + (size_t)frame * a.m_total * N;
+    float* __restrict__ img = images + (size_t)frame * a.image_stride;
+    const int slot_floats = A * 4 * rs;   // floats per staged mic
+
+    // this thread's share of the staging: row `wave` of the chunk, quad `lane` (mc <= 16 = waves)
+    auto fetch = [&](int m0, int mcc) -> float4 {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wave < mcc) {
+            const float* src = frame_sig + (size_t)mics[m0 + wave] * N;
+            if ((N & 3) == 0) {
+                if (4 * lane < N) v = reinterpret_cast<const float4*>(src)[lane];
+            } else {
+                const int k = 4 * lane;
+                if (k < N) v.x = src[k];
+                if (k + 1 < N) v.y = src[k + 1];
+                if (k + 2 < N) v.z = src[k + 2];
+                if (k + 3 < N) v.w = src[k + 3];
+            }
+        }
+        return v;
+    };
+    // table entries of one chunk for this wave's 4 directions: lane = 16 j + m  ->  LDS byte offset of the quad row
+    auto fetch_table = [&](int g0, int m0, int mcc, int& ve, float& vh) {
+        const int j = lane >> 4, m = lane & 15;
+        const int d = g0 + wave * kDpw + j;
+        ve = 0; vh = 0.0f;
+        if (m < mcc && d < tile_end) {
+            const size_t idx = (size_t)d * M + m0 + m;
+            int pd = whole[idx];
+            if constexpr (ALGO == ALGO_LERP) { pd += 1; vh = frac[idx]; }   // lerp reads s[k - p - 1]
+            ve = ((m * A * 4 + (pd & 3)) * rs + lead - (pd & ~3)) * 4;
+        }
+    };
+
+    float4 staged = fetch(0, min(mc, M));
+    int ve_next; float vh_next;
+    fetch_table(tile_begin, 0, min(mc, M), ve_next, vh_next);
+
+    for (int g0 = tile_begin; g0 < tile_end; g0 += kGroup) {
+        float acc[kDpw][4];
+#pragma unroll
+        for (int j = 0; j < kDpw; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[j][t] = 0.0f;
+
+        for (int ch = 0; ch < a.n_chunks; ++ch) {
+            const int m0 = ch * mc;
+            const int mcc = min(mc, M - m0);
+            __syncthreads();   // every wave is done with the previous contents (chunk reads or parked rows)
+            if (wave < mcc) {
+                float* row0 = lds + wave * slot_floats;
+                write_copies(row0, rs, lead, lane, staged);
+                if constexpr (ALGO == ALGO_LERP) {
+                    // D[i] = s[i+1] - s[i], the reference's own subtraction (lerp_and_sum.c:54); D[-1] stays 0 (prefix)
+                    const float nx = dpp_next(staged.x);
+                    const float4 dq = make_float4(staged.y - staged.x, staged.z - staged.y, staged.w - staged.z, nx - staged.w);
+                    write_copies(row0 + 4 * rs, rs, lead, lane, dq);
+                }
+            }
+            __syncthreads();
+            // request the next chunk (or the next group's first) while this one is consumed
+            const int ve = ve_next;
+            const float vh = vh_next;
+            {
+                int ng0 = g0, nch = ch + 1;
+                if (nch == a.n_chunks) { nch = 0; ng0 = g0 + kGroup; }
+                if (ng0 < tile_end) {
+                    const int nm0 = nch * mc;
+                    staged = fetch(nm0, min(mc, M - nm0));
+                    fetch_table(ng0, nm0, min(mc, M - nm0), ve_next, vh_next);
+                }
+            }
+            const char* lbase = reinterpret_cast<const char*>(lds) + 16 * lane;
+            auto step = [&](int j, int m) {
+                const int e = __builtin_amdgcn_readlane(ve, 16 * j + m);
+                const float4 S = *reinterpret_cast<const float4*>(lbase + e);
+                if constexpr (ALGO == ALGO_PAD) {
+                    // pad_and_sum.c:41-47   out[k] += s[k - p]
+                    acc[j][0] += S.x; acc[j][1] += S.y; acc[j][2] += S.z; acc[j][3] += S.w;
+                } else {
+                    // lerp_and_sum.c:50-56  out[k] += s[i] + h * (s[i+1] - s[i]),  i = k - p - 1
+                    const float h = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vh), 16 * j + m));
+                    const float4 Dq = *reinterpret_cast<const float4*>(lbase + e + 16 * rs);   // D copies sit 4 rows after the s copies
+                    acc[j][0] += __fmaf_rn(h, Dq.x, S.x); acc[j][1] += __fmaf_rn(h, Dq.y, S.y);
+                    acc[j][2] += __fmaf_rn(h, Dq.z, S.z); acc[j][3] += __fmaf_rn(h, Dq.w, S.w);
+                }
+            };
+            if (mcc == 16) {
+#pragma unroll
+                for (int m = 0; m < 16; ++m)
+#pragma unroll
+                    for (int j = 0; j < kDpw; ++j) step(j, m);
+            } else if (mcc == 8) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+#pragma unroll
+                    for (int j = 0; j < kDpw; ++j) step(j, m);
+            } else {
+                for (int m = 0; m < mcc; ++m) {
+                    step(0, m); step(1, m); step(2, m); step(3, m);
+                }
+            }
+        }
+
+        // ---- k-ordered mean power of this wave's 4 directions (rows alias the chunk buffer)
+        __syncthreads();
+        float* rows = lds + wave * kDpw * kParkStride;
+#pragma unroll
+        for (int j = 0; j < kDpw; ++j) {
+            float4 sq;
+            {
+                const float o0 = a.n_is_pow2 ? acc[j][0] * a.inv_n : acc[j][0] / (float)M;
+                const float o1 = a.n_is_pow2 ? acc[j][1] * a.inv_n : acc[j][1] / (float)M;
+                const float o2 = a.n_is_pow2 ? acc[j][2] * a.inv_n : acc[j][2] / (float)M;
+                const float o3 = a.n_is_pow2 ? acc[j][3] * a.inv_n : acc[j][3] / (float)M;
+                sq = make_float4(o0 * o0, o1 * o1, o2 * o2, o3 * o3);
+            }
+            reinterpret_cast<float4*>(rows + j * kParkStride)[lane] = sq;
+        }
+        if (lane < kDpw) {
+            const int d = g0 + wave * kDpw + lane;
+            if (d < tile_end) {
+                const float* row = rows + lane * kParkStride;
+                const float4* row4 = reinterpret_cast<const float4*>(row);
+                float sum = 0.0f;
+                int k = 0;
+#pragma unroll 4
+                for (; k + 4 <= N; k += 4) {
+                    const float4 v = row4[k >> 2];
+                    sum += v.x; sum += v.y; sum += v.z; sum += v.w;
+                }
+                for (; k < N; ++k) sum += row[k];
+                img[d - a.image_origin] = sum / (float)N;
+            }
+        }
+    }
+}
+
+}  // namespace copies
+
 template <int ALGO, int NC>
 hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, int frames, hipStream_t stream)
 {
@@ -482,6 +789,7 @@ hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, in
         return hipGetLastError();
     };
     if constexpr (NC == 4 && (ALGO == ALGO_PAD || ALGO == ALGO_LERP)) {
+        if (plan.layout == 2) return go(copies::das_copies_kernel<ALGO>);
         if (plan.quad) {
             switch (plan.dpw) {
                 case 1: return go(das_mimo_kernel<ALGO, 4, 1, true>);
@@ -542,6 +850,7 @@ KArgs make_args(const DasLaunch& L, const DasPlan& plan)
     a.scratch_off = plan.scratch_off; a.srow = plan.srow; a.pbw = plan.pbw;
     a.n_is_pow2 = (L.n_mics & (L.n_mics - 1)) == 0;
     a.inv_n = 1.0f / (float)L.n_mics;
+    a.debug = L.debug;
     return a;
 }
 
@@ -589,9 +898,30 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
         p.mic_chunk = mc; p.n_chunks = (L.n_mics + mc - 1) / mc;
         p.dpw = p.n_chunks > 1 ? 4 : 1;
     }
-    p.quad = (p.nc == 4 && (L.algo == ALGO_PAD || L.algo == ALGO_LERP) && !L.force_strided) ? 1 : 0;
-    p.scratch_off = round_up(p.mic_chunk * p.row_stride, 4);
-    p.lds_bytes = (size_t)p.scratch_off * sizeof(float) + scratch_bytes;
+    // Layout for pad / lerp at N <= 256: 2 = shifted copies (default), 1 = quad + DPP + scalar branch, 0 = strided.
+    const bool small_block = p.nc == 4 && (L.algo == ALGO_PAD || L.algo == ALGO_LERP);
+    p.layout = small_block ? (L.force_layout >= 0 ? L.force_layout : 2) : 0;
+    p.quad = p.layout == 1 ? 1 : 0;
+    if (p.layout == 2) {
+        const int arrays = (L.algo == ALGO_LERP) ? 2 : 1;
+        p.lead = round_up(L.tab.max_whole + 2, 4);       // lerp folds its extra sample into the delay (p + 1)
+        p.row_stride = p.lead + 256;
+        const size_t slot_bytes = (size_t)arrays * 4 * p.row_stride * sizeof(float);
+        int mc = (int)((80 * 1024) / slot_bytes);
+        mc = mc >= 16 ? 16 : mc >= 8 ? 8 : mc;
+        if (mc < 1) return fail(3);
+        if (mc > L.n_mics) mc = L.n_mics;
+        p.mic_chunk = mc; p.n_chunks = (L.n_mics + mc - 1) / mc;
+        p.waves = copies::kWaves; p.dpw = copies::kDpw; p.pbw = copies::kDpw; p.srow = copies::kParkStride;
+        p.scratch_off = 0;
+        const size_t park = (size_t)copies::kGroup * copies::kParkStride * sizeof(float);
+        const size_t buf = slot_bytes * (size_t)mc;
+        p.lds_bytes = buf > park ? buf : park;
+    }
+    if (p.layout != 2) {
+        p.scratch_off = round_up(p.mic_chunk * p.row_stride, 4);
+        p.lds_bytes = (size_t)p.scratch_off * sizeof(float) + scratch_bytes;
+    }
 
     // Tile size: enough workgroups to fill the chip a few times over, but as many directions per staged block
     // as possible.  A tile is a whole number of wave groups.
