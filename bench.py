@@ -34,7 +34,7 @@ WORKLOADS = {
     "cfg5": (256, 4, 1024, 361, 361, 8),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-LDS_PEAK_GBS = 128 * 256 * 2.4  # ds_read_b32: 128 B/clk/CU x 256 CUs x 2.4 GHz = 78.6 TB/s
+LDS_PEAK_GBS = 256 * 256 * 2.4  # ds_read_b128: 256 B/clk/CU x 256 CUs x 2.4 GHz = 157 TB/s (MI355X_MICROARCH.md, LDS table)
 
 
 def algorithmic_bytes_per_frame(algo, M, N, D, T):
@@ -198,6 +198,7 @@ def main():
         alg_bytes = frames_global * (sig_bytes + (bytes_frame - sig_bytes) * share)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         macs = frames_global * (hi - lo) * M * N
+        # LDS bytes the kernel reads per MAC: pad 4 (one sample); lerp 8 (sample + its difference); FIR flavours 4*T
         lds_bytes = macs * 4 * (2 if args.algo == "lerp" else T if args.algo in ("hybrid", "fir_vec", "fir_naive") else 1)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -216,7 +217,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "das_mimo_kernel<%s>" % args.algo, "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "table/LDS-gather kernel: the binding resource is LDS read bandwidth, not HBM (DESIGN.md section 5)",
+                         "note": "LDS-gather kernel: the tables stay L2-resident across the frames of a launch and the binding resources are "
+                                 "VALU issue and LDS reads, not HBM (DESIGN.md section 5)",
                          "lds": {"achieved": lds_bytes / (kernel_ms * 1e-3) / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
                                  "frac": lds_bytes / (kernel_ms * 1e-3) / 1e9 / LDS_PEAK_GBS},
                          "gmacs_per_s": macs / (kernel_ms * 1e-3) / 1e9},

@@ -622,7 +622,7 @@ __device__ __forceinline__ void write_copies(float* row0, int rs, int lead, int 
 }
 
 template <int ALGO>
-__global__ void __launch_bounds__(1024) das_copies_kernel(BF_TABLE_PARAMS, KArgs a)
+__global__ void __launch_bounds__(1024, 8) das_copies_kernel(BF_TABLE_PARAMS, KArgs a)   // 8 waves per SIMD = two workgroups per CU: at most 64 VGPRs
 {
     static_assert(ALGO == ALGO_PAD || ALGO == ALGO_LERP, "shifted-copies layout: pad and lerp");
     constexpr int A = (ALGO == ALGO_LERP) ? 2 : 1;   // arrays per mic: s (and D)
@@ -640,11 +640,17 @@ __global__ void __launch_bounds__(1024) das_copies_kernel(BF_TABLE_PARAMS, KArgs
     float* __restrict__ img = images + (size_t)frame * a.image_stride;
     const int slot_floats = A * 4 * rs;   // floats per staged mic
 
+    // Row of `signals` this wave stages in chunk c: mics[c*mc + wave].  Loaded once (lane c holds chunk c's row) so
+    // that the per-chunk prefetch below is a single independent load, not a load that waits for an index load.
+    int vmic = 0;
+    if (lane < a.n_chunks && lane * mc + wave < M) vmic = mics[lane * mc + wave];
+
     // this thread's share of the staging: row `wave` of the chunk, quad `lane` (mc <= 16 = waves)
-    auto fetch = [&](int m0, int mcc) -> float4 {
+    auto fetch = [&](int ch, int mcc) -> float4 {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (wave < mcc) {
-            const float* src = frame_sig + (size_t)mics[m0 + wave] * N;
+            const int mic = (ch < kWave) ? __builtin_amdgcn_readlane(vmic, ch) : mics[ch * mc + wave];
+            const float* src = frame_sig + (size_t)mic * N;
             if ((N & 3) == 0) {
                 if (4 * lane < N) v = reinterpret_cast<const float4*>(src)[lane];
             } else {
@@ -657,29 +663,39 @@ __global__ void __launch_bounds__(1024) das_copies_kernel(BF_TABLE_PARAMS, KArgs
         }
         return v;
     };
-    // table entries of one chunk for this wave's 4 directions: lane = 16 j + m  ->  LDS byte offset of the quad row
-    auto fetch_table = [&](int g0, int m0, int mcc, int& ve, float& vh) {
+    // raw table entries of one chunk for this wave's 4 directions (lane = 16 j + m); nothing here touches the loaded
+    // values, so the loads stay in flight until table_offsets() is called a chunk later
+    auto fetch_table = [&](int g0, int m0, int mcc, int& vp, float& vh) {
         const int j = lane >> 4, m = lane & 15;
         const int d = g0 + wave * kDpw + j;
-        ve = 0; vh = 0.0f;
+        vp = 0; vh = 0.0f;
         if (m < mcc && d < tile_end) {
             const size_t idx = (size_t)d * M + m0 + m;
-            int pd = whole[idx];
-            if constexpr (ALGO == ALGO_LERP) { pd += 1; vh = frac[idx]; }   // lerp reads s[k - p - 1]
-            ve = ((m * A * 4 + (pd & 3)) * rs + lead - (pd & ~3)) * 4;
+            vp = whole[idx];
+            if constexpr (ALGO == ALGO_LERP) vh = frac[idx];
         }
+    };
+    // delay -> LDS byte offset of the aligned quad row: copy (p & 3) of staged mic m, shifted back by p >> 2 quads
+    auto table_offsets = [&](int vp) -> int {
+        const int m = lane & 15;
+        int pd = vp;
+        if constexpr (ALGO == ALGO_LERP) pd += 1;   // lerp reads s[k - p - 1]
+        return ((m * A * 4 + (pd & 3)) * rs + lead - (pd & ~3)) * 4;
     };
 
     float4 staged = fetch(0, min(mc, M));
-    int ve_next; float vh_next;
-    fetch_table(tile_begin, 0, min(mc, M), ve_next, vh_next);
+    int vp_next; float vh_next;
+    fetch_table(tile_begin, 0, min(mc, M), vp_next, vh_next);
+
+    // Plain f32 VALU instructions occupy a SIMD for 4 cycles per wave64 on gfx950; the packed forms (v_pk_add_f32,
+    // v_pk_fma_f32) do two lanes' worth of IEEE-identical work in the same slot, and the kernel is VALU-issue bound,
+    // so the accumulators are kept as two float2 register pairs matching the (x,y)/(z,w) halves of a quad read.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
 
     for (int g0 = tile_begin; g0 < tile_end; g0 += kGroup) {
-        float acc[kDpw][4];
+        f32x2 acc[kDpw][2];
 #pragma unroll
-        for (int j = 0; j < kDpw; ++j)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[j][t] = 0.0f;
+        for (int j = 0; j < kDpw; ++j) { acc[j][0] = f32x2{0.0f, 0.0f}; acc[j][1] = f32x2{0.0f, 0.0f}; }
 
         for (int ch = 0; ch < a.n_chunks; ++ch) {
             const int m0 = ch * mc;
@@ -697,46 +713,47 @@ __global__ void __launch_bounds__(1024) das_copies_kernel(BF_TABLE_PARAMS, KArgs
             }
             __syncthreads();
             // request the next chunk (or the next group's first) while this one is consumed
-            const int ve = ve_next;
+            const int ve = table_offsets(vp_next);
             const float vh = vh_next;
             {
                 int ng0 = g0, nch = ch + 1;
                 if (nch == a.n_chunks) { nch = 0; ng0 = g0 + kGroup; }
                 if (ng0 < tile_end) {
                     const int nm0 = nch * mc;
-                    staged = fetch(nm0, min(mc, M - nm0));
-                    fetch_table(ng0, nm0, min(mc, M - nm0), ve_next, vh_next);
+                    staged = fetch(nch, min(mc, M - nm0));
+                    fetch_table(ng0, nm0, min(mc, M - nm0), vp_next, vh_next);
                 }
             }
             const char* lbase = reinterpret_cast<const char*>(lds) + 16 * lane;
             auto step = [&](int j, int m) {
                 const int e = __builtin_amdgcn_readlane(ve, 16 * j + m);
                 const float4 S = *reinterpret_cast<const float4*>(lbase + e);
+                const f32x2 S01{S.x, S.y}, S23{S.z, S.w};
                 if constexpr (ALGO == ALGO_PAD) {
                     // pad_and_sum.c:41-47   out[k] += s[k - p]
-                    acc[j][0] += S.x; acc[j][1] += S.y; acc[j][2] += S.z; acc[j][3] += S.w;
+                    acc[j][0] += S01; acc[j][1] += S23;
                 } else {
                     // lerp_and_sum.c:50-56  out[k] += s[i] + h * (s[i+1] - s[i]),  i = k - p - 1
                     const float h = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vh), 16 * j + m));
                     const float4 Dq = *reinterpret_cast<const float4*>(lbase + e + 16 * rs);   // D copies sit 4 rows after the s copies
-                    acc[j][0] += __fmaf_rn(h, Dq.x, S.x); acc[j][1] += __fmaf_rn(h, Dq.y, S.y);
-                    acc[j][2] += __fmaf_rn(h, Dq.z, S.z); acc[j][3] += __fmaf_rn(h, Dq.w, S.w);
+                    const f32x2 h2{h, h}, D01{Dq.x, Dq.y}, D23{Dq.z, Dq.w};
+                    acc[j][0] += __builtin_elementwise_fma(h2, D01, S01);
+                    acc[j][1] += __builtin_elementwise_fma(h2, D23, S23);
                 }
             };
-            if (mcc == 16) {
+            // 2 mics x 4 directions (pad) or 1 mic x 4 directions (lerp) of independent reads per block keeps the
+            // kernel inside the 64-VGPR budget that lets two workgroups share a CU
+            constexpr int kMb = (ALGO == ALGO_PAD) ? 2 : 1;
+            int m = 0;
+            for (; m + kMb <= mcc; m += kMb) {
 #pragma unroll
-                for (int m = 0; m < 16; ++m)
+                for (int u = 0; u < kMb; ++u)
 #pragma unroll
-                    for (int j = 0; j < kDpw; ++j) step(j, m);
-            } else if (mcc == 8) {
+                    for (int j = 0; j < kDpw; ++j) step(j, m + u);
+            }
+            for (; m < mcc; ++m) {
 #pragma unroll
-                for (int m = 0; m < 8; ++m)
-#pragma unroll
-                    for (int j = 0; j < kDpw; ++j) step(j, m);
-            } else {
-                for (int m = 0; m < mcc; ++m) {
-                    step(0, m); step(1, m); step(2, m); step(3, m);
-                }
+                for (int j = 0; j < kDpw; ++j) step(j, m);
             }
         }
 
@@ -747,10 +764,10 @@ __global__ void __launch_bounds__(1024) das_copies_kernel(BF_TABLE_PARAMS, KArgs
         for (int j = 0; j < kDpw; ++j) {
             float4 sq;
             {
-                const float o0 = a.n_is_pow2 ? acc[j][0] * a.inv_n : acc[j][0] / (float)M;
-                const float o1 = a.n_is_pow2 ? acc[j][1] * a.inv_n : acc[j][1] / (float)M;
-                const float o2 = a.n_is_pow2 ? acc[j][2] * a.inv_n : acc[j][2] / (float)M;
-                const float o3 = a.n_is_pow2 ? acc[j][3] * a.inv_n : acc[j][3] / (float)M;
+                const float o0 = a.n_is_pow2 ? acc[j][0].x * a.inv_n : acc[j][0].x / (float)M;
+                const float o1 = a.n_is_pow2 ? acc[j][0].y * a.inv_n : acc[j][0].y / (float)M;
+                const float o2 = a.n_is_pow2 ? acc[j][1].x * a.inv_n : acc[j][1].x / (float)M;
+                const float o3 = a.n_is_pow2 ? acc[j][1].y * a.inv_n : acc[j][1].y / (float)M;
                 sq = make_float4(o0 * o0, o1 * o1, o2 * o2, o3 * o3);
             }
             reinterpret_cast<float4*>(rows + j * kParkStride)[lane] = sq;
