@@ -215,7 +215,7 @@ def main():
                        "frames_per_step_global": frames_global, "directions_per_gpu": hi - lo,
                        "parallelism": "directions sharded over %d GPU(s) + RCCL all-gather of the heat-maps" % world if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "das_mimo_kernel<%s>" % args.algo, "kernel_ms": kernel_ms,
+                         "traffic": traffic, "kernel": ("copies::das_copies_kernel<%s>" if args.algo in ("pad", "lerp") and N <= 256 else "das_mimo_kernel<%s>") % args.algo, "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "LDS-gather kernel: the tables stay L2-resident across the frames of a launch and the binding resources are "
                                  "VALU issue and LDS reads, not HBM (DESIGN.md section 5)",
