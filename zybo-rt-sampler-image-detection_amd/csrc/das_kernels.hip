@@ -743,17 +743,26 @@ __global__ void __launch_bounds__(1024, 8) das_copies_kernel(BF_TABLE_PARAMS, KA
             };
             // 2 mics x 4 directions (pad) or 1 mic x 4 directions (lerp) of independent reads per block keeps the
             // kernel inside the 64-VGPR budget that lets two workgroups share a CU
-            constexpr int kMb = (ALGO == ALGO_PAD) ? 2 : 1;
-            int m = 0;
-            for (; m + kMb <= mcc; m += kMb) {
+            if constexpr (ALGO == ALGO_PAD) {
+                int m = 0;
+                for (; m + 2 <= mcc; m += 2) {
 #pragma unroll
-                for (int u = 0; u < kMb; ++u)
+                    for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int j = 0; j < kDpw; ++j) step(j, m + u);
-            }
-            for (; m < mcc; ++m) {
+                        for (int j = 0; j < kDpw; ++j) step(j, m + u);
+                }
+                for (; m < mcc; ++m) {
 #pragma unroll
-                for (int j = 0; j < kDpw; ++j) step(j, m);
+                    for (int j = 0; j < kDpw; ++j) step(j, m);
+                }
+            } else {
+                // lerp holds two quads per read pair: two directions at a time (16 VGPRs of reads in flight)
+                for (int m = 0; m < mcc; ++m) {
+                    step(0, m); step(1, m);
+                    __builtin_amdgcn_sched_barrier(0);
+                    step(2, m); step(3, m);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
 
