@@ -122,6 +122,15 @@ void bf_publish_frame(const float *signals);
 int bf_das_device(int algo, const float *d_signals, int m_total, float *d_images, int image_stride, int frames,
                   const int *adaptive_array, int n, int dir_begin, int dir_end, void *stream);
 
+/* ---- ingest: FPGA protocol-v2 datagrams -> the mic-major float32 frame the beamformers read (PC/src/receiver.c:94-151,
+ * `receive_and_write_to_buffer`).  `packets` holds N_SAMPLES datagrams back to back, each
+ * { u16 frequency; i8 n_arrays; i8 protocol_ver; i32 counter; i32 stream[N_MICROPHONES]; } (receiver.h:51-59).
+ * Writes n_arrays*rows*columns mic rows of N_SAMPLES floats; rows/columns are the 8 x 8 tile of config.json:7-8.
+ * bf_ingest takes host pointers (copies both ways); bf_ingest_device takes HIP device pointers and only enqueues.
+ * The one element the reference reads past the end of the datagram (last array, last row, x = 0) is defined as 0. */
+int bf_ingest(const void *packets, int n_arrays, int rows, int columns, float *frame);
+int bf_ingest_device(const void *d_packets, int n_arrays, int rows, int columns, float *d_frame, void *stream);
+
 /* Launch geometry the planner picks for a call like the above (no GPU needed): out[0..9] = nc, lead,
  * row_stride, mic_chunk, n_chunks, waves, dpw, tile_dirs, n_tiles, lds_bytes.  Returns 0 or -1. */
 int bf_plan_das(int algo, int n, int frames, int dir_begin, int dir_end, int max_whole, int n_cus, long long out[10]);

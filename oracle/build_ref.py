@@ -44,6 +44,9 @@ def build(name, cfg, outdir):
         out = os.path.join(outdir, "libref_%s.so" % name)
         srcs = [os.path.join(REF, "src", "algorithms", u) for u in UNITS]
         subprocess.check_call(["gcc"] + CFLAGS + ["-I", os.path.join(scratch, "src")] + srcs + ["-lm", "-o", out])
+        # the receiver's datagram -> frame conversion (receiver.c:94-151); needs only libc sockets
+        rcv = os.path.join(outdir, "libref_receiver_%s.so" % name)
+        subprocess.check_call(["gcc"] + CFLAGS + ["-I", os.path.join(scratch, "src"), os.path.join(REF, "src", "receiver.c"), "-o", rcv])
         return out
     finally:
         shutil.rmtree(scratch, ignore_errors=True)

@@ -253,6 +253,31 @@ void oracle_mimo_convolve_hybrid(const float *signals, float *image, const int *
     free(out);
 }
 
+/* ---------------------------------------------------------------- ingest (PC/src/receiver.c:94-151) */
+
+/* FPGA protocol-v2 datagrams -> mic-major float frame.  `packets` = n_samples datagrams of (8 + 4*n_microphones) bytes
+ * (receiver.h:51-59).  Restates receive_and_write_to_buffer / receive_to_buffer without the socket: datagram `step` is
+ * what the step-th recv() returned.  The reference's odd-row index `row + COLUMNS - x` reads stream[n_microphones] (one
+ * int past the datagram) for the very last row when every array is present; that element is written as 0 here. */
+void oracle_ingest(const unsigned char *packets, int n_samples, int n_microphones, int n_arrays, int rows, int columns, float *data)
+{
+    const size_t stride = 8 + 4 * (size_t)n_microphones;
+    for (int step = 0; step < n_samples; step++) {
+        const int *stream = (const int *)(packets + step * stride + 8);
+        int s = 0;
+        for (int n = 0; n < n_arrays; n++)
+            for (int y = 0; y < rows; y++) {
+                int row = n * rows * columns + y * columns;
+                for (int x = 0; x < columns; x++) {
+                    int idx = (y % 2) == 0 ? row + x : row + columns - x;
+                    int v = idx < n_microphones ? stream[idx] : 0;
+                    data[step + (size_t)n_samples * s] = (float)((double)v / 16777216.0);   /* NORM_FACTOR, config.json:52 */
+                    s++;
+                }
+            }
+    }
+}
+
 /* ---------------------------------------------------------------- helpers for tests / the bench's cpu_baseline leg */
 
 /* mean power of a raw steered block (exposes block_power; `out` is overwritten with out/n as in the reference) */

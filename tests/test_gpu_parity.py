@@ -312,3 +312,31 @@ def test_api_shims(nat):
     nat.lib.mimo_truncated(nat.fptr(img_c), nat.iptr(mics), M); nat.check()
     nat.lib.mimo_pad(nat.fptr(sig), nat.fptr(img_b), nat.iptr(mics), M); nat.check()
     assert np.array_equal(img_c, img_b)
+
+
+def test_beamformer_module_surface(nat, oracle_lib):
+    """lib.beamformer (PC/src/main.pyx names): publish -> receive, producer loop `b`, steering offset, MISO listen."""
+    import queue as pyqueue
+    from lib import beamformer as B
+    c = util.configure("shipped")
+    M, N, X, Y = c["M"], c["N"], c["X"], c["Y"]
+    sig = util.inputs("shipped")["s3"]
+    B.connect(replay_mode=True, verbose=False)
+    B.publish(sig)
+    seen = np.empty((M, N), dtype=np.float32)
+    B.receive(seen)
+    q = pyqueue.Queue()
+    B.b(q, True, max_frames=2)
+    (img, nr), (img2, nr2) = q.get(), q.get()
+    assert (nr, nr2) == (1, 2) and img.shape == (X, Y) and np.array_equal(img, img2)
+    whole = util.table_for("pad", "shipped")
+    orc = oracle_lib.Oracle(N, X, Y, c["T"])
+    want = orc.mimo_pad(seen, whole, np.arange(M, dtype=np.int32))
+    assert img.tobytes() == want.tobytes()
+    # steering: (azimuth, elevation) degrees -> flat offset, main.pyx:498-515
+    off = B.steer_cartesian_degree(0, 0)
+    assert off == int((Y // 2) * X * M + int(0.5 * X) * M)
+    nat.lib.load_coefficients_pad(nat.iptr(whole.ravel()), whole.size); nat.check()
+    out = B.listen()
+    assert out.tobytes() == orc.miso_pad(seen, whole, np.arange(M, dtype=np.int32), off).tobytes()
+    B.disconnect()

@@ -759,6 +759,48 @@ int bf_das_device(int algo, const float* d_signals, int m_total, float* d_images
     return HIP_OK(bf::launch_das(L, plan, reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
 }
 
+// ---------------------------------------------------------------- ingest (receiver.c:94-151)
+
+static int ingest_common(const void* d_packets, int n_arrays, int rows, int columns, float* d_frame, hipStream_t stream)
+{
+    State& s = S();
+    const int mics_out = n_arrays * rows * columns;
+    if (n_arrays < 1 || rows < 1 || columns < 1 || mics_out > s.sz.n_microphones) {
+        set_error("bf_ingest: n_arrays*rows*columns = %d does not fit N_MICROPHONES = %d", mics_out, s.sz.n_microphones);
+        return -1;
+    }
+    const int stride = 8 + 4 * s.sz.n_microphones;   // sizeof(msg), receiver.h:51-59
+    return HIP_OK(bf::launch_ingest(d_packets, stride, 8, s.sz.n_samples, mics_out, s.sz.n_microphones, rows, columns, d_frame, stream)) ? 0 : -1;
+}
+
+int bf_ingest_device(const void* d_packets, int n_arrays, int rows, int columns, float* d_frame, void* stream)
+{
+    std::lock_guard<std::mutex> lock(S().mu);
+    sizes_from_env_once();
+    if (!d_packets || !d_frame) { set_error("bf_ingest_device: null argument"); return -1; }
+    if (!ensure_device()) return -1;
+    return ingest_common(d_packets, n_arrays, rows, columns, d_frame, reinterpret_cast<hipStream_t>(stream));
+}
+
+int bf_ingest(const void* packets, int n_arrays, int rows, int columns, float* frame)
+{
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    sizes_from_env_once();
+    if (!packets || !frame) { set_error("bf_ingest: null argument"); return -1; }
+    const size_t out_n = (size_t)std::max(0, n_arrays * rows * columns) * s.sz.n_samples;
+    if (!ensure_device()) { poison(frame, out_n); return -1; }
+    const size_t in_bytes = (size_t)(8 + 4 * s.sz.n_microphones) * s.sz.n_samples;
+    static DevBuf<unsigned char> d_in;
+    bool ok = HIP_OK(d_in.reserve(in_bytes)) && HIP_OK(s.d_frame.reserve(out_n ? out_n : 1));
+    ok = ok && HIP_OK(hipMemcpyAsync(d_in.p, packets, in_bytes, hipMemcpyHostToDevice, s.stream));
+    ok = ok && ingest_common(d_in.p, n_arrays, rows, columns, s.d_frame.p, s.stream) == 0;
+    ok = ok && HIP_OK(hipMemcpyAsync(frame, s.d_frame.p, out_n * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+    ok = ok && HIP_OK(hipStreamSynchronize(s.stream));
+    if (!ok) poison(frame, out_n);
+    return ok ? 0 : -1;
+}
+
 int bf_plan_das(int algo, int n, int frames, int dir_begin, int dir_end, int max_whole, int n_cus, long long out[10])
 {
     State& s = S();

@@ -74,4 +74,8 @@ hipError_t launch_das(const DasLaunch& L, const DasPlan& plan, hipStream_t strea
 hipError_t launch_miso(const DasLaunch& L, const DasPlan& plan, long long row_offset, const float* init_dev, float* out_dev,
                        hipStream_t stream);
 
+// FPGA protocol-v2 datagrams (one per sample instant) -> float32 [n_mics_out][n_samples] mic-major frame (receiver.c:94-151).
+hipError_t launch_ingest(const void* d_packets, int packet_stride, int header_bytes, int n_samples, int n_mics_out, int stream_len,
+                         int rows, int columns, float* d_frame, hipStream_t stream);
+
 }  // namespace bf
