@@ -131,6 +131,23 @@ int bf_das_device(int algo, const float *d_signals, int m_total, float *d_images
 int bf_ingest(const void *packets, int n_arrays, int rows, int columns, float *frame);
 int bf_ingest_device(const void *d_packets, int n_arrays, int rows, int columns, float *d_frame, void *stream);
 
+/* ---- heat-map post-processing on the device (PC/src/visual.py; display side of the path) ----
+ * bf_heatmap_colorize_device: visual.py:143-185 -- d_power float32 [frames][MAX_RES_X*MAX_RES_Y] -> d_small uint8
+ *   [frames][MAX_RES_Y][MAX_RES_X][3] (reversed-jet colours, flipped as the reference indexes it) and should_overlay flags.
+ *   Reference defaults: threshold 1e-7, amount 0.5, exponent 5.
+ * bf_heatmap_overlay_device: cv2.resize(INTER_LINEAR) to out_w x out_h (:186), res = w_prev*prev + w_new*new (:450, 0.5/0.5;
+ *   d_prev uint8 [out_h][out_w][3] is the carried state, updated in place), then onto the camera frames
+ *   w_cam*frame + w_heat*res (:452, 0.9/0.9) when d_camera is not NULL.  d_out uint8 [frames][out_h][out_w][3].
+ * bf_power_center_device: find_power_center (:295-322) -> d_centers float32 [frames][2] = (center_x, center_y);
+ *   d_workspace float32 [frames][MAX_RES_X*MAX_RES_Y].
+ * All take HIP device pointers and a stream and only enqueue. */
+int bf_heatmap_colorize_device(const float *d_power, int frames, float threshold, float amount, float exponent,
+                               unsigned char *d_small, int *d_should_overlay, void *stream);
+int bf_heatmap_overlay_device(const unsigned char *d_small, int frames, int out_w, int out_h, unsigned char *d_prev,
+                              const unsigned char *d_camera, unsigned char *d_out, float w_prev, float w_new, float w_cam,
+                              float w_heat, void *stream);
+int bf_power_center_device(const float *d_power, int frames, float *d_centers, float *d_workspace, void *stream);
+
 /* Launch geometry the planner picks for a call like the above (no GPU needed): out[0..9] = nc, lead,
  * row_stride, mic_chunk, n_chunks, waves, dpw, tile_dirs, n_tiles, lds_bytes.  Returns 0 or -1. */
 int bf_plan_das(int algo, int n, int frames, int dir_begin, int dir_end, int max_whole, int n_cus, long long out[10]);

@@ -801,6 +801,42 @@ int bf_ingest(const void* packets, int n_arrays, int rows, int columns, float* f
     return ok ? 0 : -1;
 }
 
+// ---------------------------------------------------------------- heat-map post-processing (visual.py)
+
+int bf_heatmap_colorize_device(const float* d_power, int frames, float threshold, float amount, float exponent, unsigned char* d_small,
+                               int* d_should_overlay, void* stream)
+{
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    sizes_from_env_once();
+    if (!d_power || !d_small || !d_should_overlay || frames < 1) { set_error("bf_heatmap_colorize_device: null argument or frames < 1"); return -1; }
+    if (!ensure_device()) return -1;
+    return HIP_OK(bf::launch_colorize(d_power, frames, s.sz.res_x, s.sz.res_y, threshold, amount, exponent, d_small, d_should_overlay,
+                                      reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
+}
+
+int bf_heatmap_overlay_device(const unsigned char* d_small, int frames, int out_w, int out_h, unsigned char* d_prev, const unsigned char* d_camera,
+                              unsigned char* d_out, float w_prev, float w_new, float w_cam, float w_heat, void* stream)
+{
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    sizes_from_env_once();
+    if (!d_small || !d_prev || !d_out || frames < 1 || out_w < 1 || out_h < 1) { set_error("bf_heatmap_overlay_device: bad argument"); return -1; }
+    if (!ensure_device()) return -1;
+    return HIP_OK(bf::launch_overlay(d_small, frames, s.sz.res_x, s.sz.res_y, out_w, out_h, d_prev, d_camera, d_out, w_prev, w_new, w_cam, w_heat,
+                                     reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
+}
+
+int bf_power_center_device(const float* d_power, int frames, float* d_centers, float* d_workspace, void* stream)
+{
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    sizes_from_env_once();
+    if (!d_power || !d_centers || !d_workspace || frames < 1) { set_error("bf_power_center_device: bad argument"); return -1; }
+    if (!ensure_device()) return -1;
+    return HIP_OK(bf::launch_power_center(d_power, frames, s.sz.res_x, s.sz.res_y, d_centers, d_workspace, reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
+}
+
 int bf_plan_das(int algo, int n, int frames, int dir_begin, int dir_end, int max_whole, int n_cus, long long out[10])
 {
     State& s = S();

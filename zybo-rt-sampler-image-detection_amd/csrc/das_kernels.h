@@ -78,4 +78,12 @@ hipError_t launch_miso(const DasLaunch& L, const DasPlan& plan, long long row_of
 hipError_t launch_ingest(const void* d_packets, int packet_stride, int header_bytes, int n_samples, int n_mics_out, int stream_len,
                          int rows, int columns, float* d_frame, hipStream_t stream);
 
+// heat-map post-processing (PC/src/visual.py:143-188, 295-322, 450-452); see heatmap_kernels.hip
+hipError_t launch_colorize(const float* d_power, int frames, int res_x, int res_y, float threshold, float amount, float exponent,
+                           unsigned char* d_small, int* d_overlay, hipStream_t stream);
+hipError_t launch_overlay(const unsigned char* d_small, int frames, int small_w, int small_h, int out_w, int out_h, unsigned char* d_prev,
+                          const unsigned char* d_camera, unsigned char* d_out, float w_prev, float w_new, float w_cam, float w_heat,
+                          hipStream_t stream);
+hipError_t launch_power_center(const float* d_power, int frames, int rows, int cols, float* d_centers, float* d_workspace, hipStream_t stream);
+
 }  // namespace bf

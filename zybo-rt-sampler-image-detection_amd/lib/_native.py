@@ -82,6 +82,9 @@ _sig("bf_das_device", C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int
 _sig("bf_plan_das", C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong))
 _sig("bf_ingest", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, FP)
 _sig("bf_ingest_device", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+_sig("bf_heatmap_colorize_device", C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p)
+_sig("bf_heatmap_overlay_device", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p)
+_sig("bf_power_center_device", C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 _sig("bf_get_lerp_tables", C.c_int, IP, FP, C.c_int)
 _sig("bf_get_hybrid_tables", C.c_int, IP, FP, C.c_int)
 _sig("bf_default_geometry", None, C.POINTER(Geometry))
