@@ -148,6 +148,28 @@ int bf_heatmap_overlay_device(const unsigned char *d_small, int frames, int out_
                               float w_heat, void *stream);
 int bf_power_center_device(const float *d_power, int frames, float *d_centers, float *d_workspace, void *stream);
 
+/* ---- frequency-domain beamformers (device pointers, enqueue only) ----
+ * Delay-and-sum by phase steering: PC/application/realtime_scripts/beam_forming_algorithm.py:30-70 with the steering
+ * phasors of calc_phase_shift_cartesian.py:37-50.  MVDR has no counterpart in the reference (builder-defined, see
+ * DESIGN.md).  n_bins rFFT bins starting at bin_lo; planes are float32, complex values as separate re / im arrays.
+ *   bf_fd_steering_device   a[k][m][d] = exp(-j 2 pi freq[k] tau[d][m])   (tau seconds, float64 [D][M]; freq Hz, float64 [K])
+ *   bf_fd_dft_device        rfft of every active mic row of every frame -> X as [K][M][F] and as [K][F][M]
+ *   bf_fd_das_power_device  P[f][d] = sum_k | sum_m X[k][m][f] a[k][m][d] |^2                                    -> float32 [F][D]
+ *   bf_fd_covariance_device R[k] = (1/F) sum_f x x^H                                                              -> [K][M][M]
+ *   bf_fd_cholesky_inverse_device  R += loading*tr(R)/M*I = L L^H;  writes inverse(L) transposed [K][col][row];  M <= 128;
+ *                           d_status int32 [K] (zeroed by the caller) receives j+1 where a pivot was not positive
+ *   bf_fd_mvdr_power_device P[d] = sum_k 1 / || inverse(L_k) a[k][:, d] ||^2                                     -> float32 [D]  */
+int bf_fd_steering_device(const double *d_tau, const double *d_freq, int n_dirs, int n_mics, int n_bins, float *d_are, float *d_aim, void *stream);
+int bf_fd_dft_device(const float *d_frames, int m_total, int frames, const int *adaptive_array, int n, int bin_lo, int n_bins,
+                     float *d_xre_mf, float *d_xim_mf, float *d_xre_fm, float *d_xim_fm, void *stream);
+int bf_fd_das_power_device(const float *d_xre_mf, const float *d_xim_mf, const float *d_are, const float *d_aim, int frames, int n_mics,
+                           int n_dirs, int n_bins, float *d_power, void *stream);
+int bf_fd_covariance_device(const float *d_xre_fm, const float *d_xim_fm, int frames, int n_mics, int n_bins, float *d_rre, float *d_rim, void *stream);
+int bf_fd_cholesky_inverse_device(const float *d_rre, const float *d_rim, int n_mics, int n_bins, float loading, float *d_lire_t, float *d_liim_t,
+                                  int *d_status, void *stream);
+int bf_fd_mvdr_power_device(const float *d_lire_t, const float *d_liim_t, const float *d_are, const float *d_aim, int n_mics, int n_dirs,
+                            int n_bins, float *d_power, void *stream);
+
 /* Launch geometry the planner picks for a call like the above (no GPU needed): out[0..9] = nc, lead,
  * row_stride, mic_chunk, n_chunks, waves, dpw, tile_dirs, n_tiles, lds_bytes.  Returns 0 or -1. */
 int bf_plan_das(int algo, int n, int frames, int dir_begin, int dir_end, int max_whole, int n_cus, long long out[10]);

@@ -837,6 +837,63 @@ int bf_power_center_device(const float* d_power, int frames, float* d_centers, f
     return HIP_OK(bf::launch_power_center(d_power, frames, s.sz.res_x, s.sz.res_y, d_centers, d_workspace, reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
 }
 
+// ---------------------------------------------------------------- frequency-domain beamformers
+
+#define FD_ENTER(cond, name)                                                     \
+    State& s = S();                                                              \
+    std::lock_guard<std::mutex> lock(s.mu);                                      \
+    sizes_from_env_once();                                                       \
+    if (!(cond)) { set_error(name ": null pointer or non-positive size"); return -1; } \
+    if (!ensure_device()) return -1;                                             \
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+
+int bf_fd_steering_device(const double* d_tau, const double* d_freq, int n_dirs, int n_mics, int n_bins, float* d_are, float* d_aim, void* stream)
+{
+    FD_ENTER(d_tau && d_freq && d_are && d_aim && n_dirs > 0 && n_mics > 0 && n_bins > 0, "bf_fd_steering_device")
+    return HIP_OK(bf::launch_fd_steering(d_tau, d_freq, n_dirs, n_mics, n_bins, d_are, d_aim, st)) ? 0 : -1;
+}
+
+int bf_fd_dft_device(const float* d_frames, int m_total, int frames, const int* adaptive_array, int n, int bin_lo, int n_bins, float* d_xre_mf,
+                     float* d_xim_mf, float* d_xre_fm, float* d_xim_fm, void* stream)
+{
+    FD_ENTER(d_frames && adaptive_array && d_xre_mf && d_xim_mf && d_xre_fm && d_xim_fm && frames > 0 && n > 0 && n_bins > 0 && bin_lo >= 0,
+             "bf_fd_dft_device")
+    if (bin_lo + n_bins > s.sz.n_samples / 2 + 1) { set_error("bf_fd_dft_device: bins [%d,%d) exceed N_SAMPLES/2+1 = %d", bin_lo, bin_lo + n_bins, s.sz.n_samples / 2 + 1); return -1; }
+    int max_row = 0;
+    if (!upload_mics(adaptive_array, n, &max_row)) return -1;
+    if (max_row >= m_total) { set_error("bf_fd_dft_device: adaptive_array names row %d but frames have %d rows", max_row, m_total); return -1; }
+    return HIP_OK(bf::launch_fd_dft(d_frames, s.d_mics.p, m_total, s.sz.n_samples, frames, n, bin_lo, n_bins, d_xre_mf, d_xim_mf, d_xre_fm, d_xim_fm, st)) ? 0 : -1;
+}
+
+int bf_fd_das_power_device(const float* d_xre_mf, const float* d_xim_mf, const float* d_are, const float* d_aim, int frames, int n_mics, int n_dirs,
+                           int n_bins, float* d_power, void* stream)
+{
+    FD_ENTER(d_xre_mf && d_xim_mf && d_are && d_aim && d_power && frames > 0 && n_mics > 0 && n_dirs > 0 && n_bins > 0, "bf_fd_das_power_device")
+    return HIP_OK(bf::launch_fd_das_power(d_xre_mf, d_xim_mf, d_are, d_aim, frames, n_mics, n_dirs, n_bins, d_power, st)) ? 0 : -1;
+}
+
+int bf_fd_covariance_device(const float* d_xre_fm, const float* d_xim_fm, int frames, int n_mics, int n_bins, float* d_rre, float* d_rim, void* stream)
+{
+    FD_ENTER(d_xre_fm && d_xim_fm && d_rre && d_rim && frames > 0 && n_mics > 0 && n_bins > 0, "bf_fd_covariance_device")
+    return HIP_OK(bf::launch_fd_covariance(d_xre_fm, d_xim_fm, frames, n_mics, n_bins, d_rre, d_rim, st)) ? 0 : -1;
+}
+
+int bf_fd_cholesky_inverse_device(const float* d_rre, const float* d_rim, int n_mics, int n_bins, float loading, float* d_lire_t, float* d_liim_t,
+                                  int* d_status, void* stream)
+{
+    FD_ENTER(d_rre && d_rim && d_lire_t && d_liim_t && d_status && n_mics > 0 && n_bins > 0, "bf_fd_cholesky_inverse_device")
+    if (n_mics > 128) { set_error("bf_fd_cholesky_inverse_device: %d mics; the in-LDS factorisation handles at most 128", n_mics); return -1; }
+    return HIP_OK(bf::launch_fd_cholesky_inverse(d_rre, d_rim, n_mics, n_bins, loading, d_lire_t, d_liim_t, d_status, st)) ? 0 : -1;
+}
+
+int bf_fd_mvdr_power_device(const float* d_lire_t, const float* d_liim_t, const float* d_are, const float* d_aim, int n_mics, int n_dirs, int n_bins,
+                            float* d_power, void* stream)
+{
+    FD_ENTER(d_lire_t && d_liim_t && d_are && d_aim && d_power && n_mics > 0 && n_dirs > 0 && n_bins > 0, "bf_fd_mvdr_power_device")
+    if (n_mics > 128) { set_error("bf_fd_mvdr_power_device: %d mics; at most 128", n_mics); return -1; }
+    return HIP_OK(bf::launch_fd_mvdr_power(d_lire_t, d_liim_t, d_are, d_aim, n_mics, n_dirs, n_bins, d_power, st)) ? 0 : -1;
+}
+
 int bf_plan_das(int algo, int n, int frames, int dir_begin, int dir_end, int max_whole, int n_cus, long long out[10])
 {
     State& s = S();

@@ -86,4 +86,17 @@ hipError_t launch_overlay(const unsigned char* d_small, int frames, int small_w,
                           hipStream_t stream);
 hipError_t launch_power_center(const float* d_power, int frames, int rows, int cols, float* d_centers, float* d_workspace, hipStream_t stream);
 
+// frequency-domain beamformers (freq_kernels.hip): steering phasors, DFT of the selected bins, and the MFMA complex GEMM
+// with its three epilogues (phase-steer DAS power, covariance, MVDR quadratic form) plus the per-bin Cholesky inverse.
+hipError_t launch_fd_steering(const double* d_tau, const double* d_freq, int n_dirs, int n_mics, int n_bins, float* d_are, float* d_aim, hipStream_t stream);
+hipError_t launch_fd_dft(const float* d_frames, const int32_t* d_mics, int m_total, int n_samples, int n_frames, int n_mics, int bin_lo, int n_bins,
+                         float* xre_mf, float* xim_mf, float* xre_fm, float* xim_fm, hipStream_t stream);
+hipError_t launch_fd_das_power(const float* xre_mf, const float* xim_mf, const float* are, const float* aim, int n_frames, int n_mics, int n_dirs,
+                               int n_bins, float* d_power, hipStream_t stream);
+hipError_t launch_fd_covariance(const float* xre_fm, const float* xim_fm, int n_frames, int n_mics, int n_bins, float* rre, float* rim, hipStream_t stream);
+hipError_t launch_fd_cholesky_inverse(const float* rre, const float* rim, int n_mics, int n_bins, float loading, float* lire_t, float* liim_t,
+                                      int* d_status, hipStream_t stream);
+hipError_t launch_fd_mvdr_power(const float* lire_t, const float* liim_t, const float* are, const float* aim, int n_mics, int n_dirs, int n_bins,
+                                float* d_power, hipStream_t stream);
+
 }  // namespace bf

@@ -1,0 +1,304 @@
+// freq_kernels.hip -- frequency-domain (phase-steered) beamformers on gfx950: delay-and-sum and MVDR.
+//
+// Reference for the delay-and-sum flavour: PC/application/realtime_scripts/beam_forming_algorithm.py:30-70 and
+// calc_phase_shift_cartesian.py:37-50 (NumPy, complex128):
+//     X = rfft(signal, axis=0)[bins];  B[k, d] = sum_m X[k, m] * exp(-j 2 pi f_k tau[d, m]);  P[d] = sum_k |B[k, d]|^2
+// MVDR (BASELINE.json config 3) has NO counterpart in the reference; it is defined here as
+//     R_k = (1/F) sum_frames x x^H + delta * tr(R_k)/M * I;   P[d] = sum_k 1 / (a_{k,d}^H R_k^{-1} a_{k,d})
+// with the same steering vectors a_{k,d}[m] = exp(-j 2 pi f_k tau[d, m]).
+//
+// This is the only GEMM-shaped work in the repository, so it is the only place MFMA is used: one complex-GEMM
+// kernel built on v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit-wise an fmaf chain, no reduced precision),
+// specialised by its epilogue:
+//     EPI_POWER   C = X_k^T A_k      (frames x dirs)  ->  P[f, d] += |C|^2 over the bins      (phase-steer DAS)
+//     EPI_STORE   C = X_k X_k^H / F  (mics x mics)    ->  R_k                                  (covariance)
+//     EPI_MVDR    C = L_k^-1 A_k     (mics x dirs)    ->  P[d] += 1 / sum_m |C[m, d]|^2         (MVDR quadratic form)
+// Operands are stored as separate re / im planes, K-major with the tile index contiguous ([batch][k][i]), so that the
+// MFMA lane map (A: lane l holds A[i = l & 31][k = l >> 5]; B: B[k = l >> 5][j = l & 31]) reads 128-byte rows.
+// A complex product is four real MFMAs; conj(B) is a sign flip of the loaded imaginary part.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bf {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { EPI_POWER = 0, EPI_STORE = 1, EPI_MVDR = 2 };
+
+struct GemmArgs {
+    const float* a_re; const float* a_im;   // [batch][K][I]
+    const float* b_re; const float* b_im;   // [batch][K][J]
+    float* out0; float* out1;               // EPI_POWER: P[I][J] (out0);  EPI_STORE: C planes [batch][I][J];  EPI_MVDR: P[J] (out0)
+    int I, J, K, batch;
+    int conj_b;
+    float scale;                            // EPI_STORE: C *= scale
+};
+
+// C/D lane map of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// One wave per 32 x 32 tile of C; 4 waves (4 column tiles) per workgroup.
+template <int EPI>
+__global__ void __launch_bounds__(256) cgemm_kernel(GemmArgs g)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int i0 = blockIdx.y * 32;
+    const int j0 = (blockIdx.x * 4 + wave) * 32;
+    if (j0 >= g.J) return;
+    const int li = lane & 31, lk = lane >> 5;
+    const bool ai_ok = i0 + li < g.I, bj_ok = j0 + li < g.J;
+
+    f32x16 acc_p;   // EPI_POWER: running |C|^2 over the batch (bins)
+    float inv_sum = 0.0f;   // EPI_MVDR
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_p[r] = 0.0f;
+
+    const int b_begin = (EPI == EPI_STORE) ? blockIdx.z : 0;
+    const int b_end = (EPI == EPI_STORE) ? blockIdx.z + 1 : g.batch;
+
+    for (int b = b_begin; b < b_end; ++b) {
+        // EPI_MVDR needs all I rows of a column: loop the row tiles inside (I <= 128 -> up to 4 tiles)
+        const int row_tiles = (EPI == EPI_MVDR) ? (g.I + 31) / 32 : 1;
+        float colsum = 0.0f;
+        for (int rt = 0; rt < row_tiles; ++rt) {
+            const int ib = (EPI == EPI_MVDR) ? rt * 32 : i0;
+            const bool a_ok = (EPI == EPI_MVDR) ? (ib + li < g.I) : ai_ok;
+            f32x16 cre, cim;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { cre[r] = 0.0f; cim[r] = 0.0f; }
+            const float* are = g.a_re + ((size_t)b * g.K) * g.I + ib + li;
+            const float* aim = g.a_im + ((size_t)b * g.K) * g.I + ib + li;
+            const float* bre = g.b_re + ((size_t)b * g.K) * g.J + j0 + li;
+            const float* bim = g.b_im + ((size_t)b * g.K) * g.J + j0 + li;
+            for (int k = 0; k < g.K; k += 2) {
+                const int kk = k + lk;
+                const bool k_ok = kk < g.K;
+                const float xr = (a_ok && k_ok) ? are[(size_t)kk * g.I] : 0.0f;
+                const float xi = (a_ok && k_ok) ? aim[(size_t)kk * g.I] : 0.0f;
+                const float yr = (bj_ok && k_ok) ? bre[(size_t)kk * g.J] : 0.0f;
+                float yi = (bj_ok && k_ok) ? bim[(size_t)kk * g.J] : 0.0f;
+                if (g.conj_b) yi = -yi;
+                // (xr + j xi)(yr + j yi)
+                cre = __builtin_amdgcn_mfma_f32_32x32x2f32(xr, yr, cre, 0, 0, 0);
+                cre = __builtin_amdgcn_mfma_f32_32x32x2f32(-xi, yi, cre, 0, 0, 0);
+                cim = __builtin_amdgcn_mfma_f32_32x32x2f32(xr, yi, cim, 0, 0, 0);
+                cim = __builtin_amdgcn_mfma_f32_32x32x2f32(xi, yr, cim, 0, 0, 0);
+            }
+            if constexpr (EPI == EPI_POWER) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_p[r] += cre[r] * cre[r] + cim[r] * cim[r];
+            } else if constexpr (EPI == EPI_STORE) {
+                const int col = j0 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = ib + acc_row(r, lane);
+                    if (row < g.I && col < g.J) {
+                        const size_t o = ((size_t)b * g.I + row) * g.J + col;
+                        g.out0[o] = cre[r] * g.scale;
+                        g.out1[o] = cim[r] * g.scale;
+                    }
+                }
+            } else {
+                float s = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += cre[r] * cre[r] + cim[r] * cim[r];   // rows outside I were zero operands
+                colsum += s;
+            }
+        }
+        if constexpr (EPI == EPI_MVDR) {
+            colsum += __shfl_xor(colsum, 32, 64);      // the other half of the rows of this column
+            inv_sum += 1.0f / colsum;
+        }
+    }
+    if constexpr (EPI == EPI_POWER) {
+        const int col = j0 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = i0 + acc_row(r, lane);
+            if (row < g.I && col < g.J) g.out0[(size_t)row * g.J + col] = acc_p[r];
+        }
+    } else if constexpr (EPI == EPI_MVDR) {
+        if (lane < 32 && j0 + li < g.J) g.out0[j0 + li] = inv_sum;
+    }
+}
+
+// X[k][.] = sum_n s[n] exp(-2 pi j k n / N) for the bins [bin_lo, bin_hi) (numpy.fft.rfft semantics), direct DFT with an
+// LDS twiddle table.  One workgroup per (frame, mic); thread t owns bin bin_lo + t.  Writes both operand layouts the
+// GEMMs need: [K][M][F] (mic-major, frames contiguous) and [K][F][M] (frame-major, mics contiguous).
+__global__ void __launch_bounds__(128) dft_kernel(const float* __restrict__ frames, const int32_t* __restrict__ mics, int m_total, int n_samples,
+                                                  int n_frames, int n_mics, int bin_lo, int n_bins, float* __restrict__ xre_mf,
+                                                  float* __restrict__ xim_mf, float* __restrict__ xre_fm, float* __restrict__ xim_fm)
+{
+    extern __shared__ float tw[];   // cos[N], sin[N], then the signal row [N]
+    float* tc = tw;
+    float* ts = tw + n_samples;
+    float* sg = tw + 2 * n_samples;
+    const int f = blockIdx.x / n_mics, m = blockIdx.x - f * n_mics;
+    const float* row = frames + ((size_t)f * m_total + mics[m]) * n_samples;
+    for (int n = threadIdx.x; n < n_samples; n += blockDim.x) {
+        const double ang = -2.0 * 3.14159265358979323846 * (double)n / (double)n_samples;
+        tc[n] = (float)cos(ang);
+        ts[n] = (float)sin(ang);
+        sg[n] = row[n];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < n_bins; t += blockDim.x) {
+        const int k = bin_lo + t;
+        float re = 0.0f, im = 0.0f;
+        int idx = 0;
+        for (int n = 0; n < n_samples; ++n) {
+            const float s = sg[n];
+            re = fmaf(s, tc[idx], re);
+            im = fmaf(s, ts[idx], im);
+            idx += k;
+            if (idx >= n_samples) idx -= n_samples * (idx / n_samples);
+        }
+        xre_mf[((size_t)t * n_mics + m) * n_frames + f] = re;
+        xim_mf[((size_t)t * n_mics + m) * n_frames + f] = im;
+        xre_fm[((size_t)t * n_frames + f) * n_mics + m] = re;
+        xim_fm[((size_t)t * n_frames + f) * n_mics + m] = im;
+    }
+}
+
+// a[k][m][d] = exp(-j 2 pi f_k tau[d][m]), evaluated in float64 and stored as float32 planes.
+__global__ void __launch_bounds__(256) steering_kernel(const double* __restrict__ tau, const double* __restrict__ freq, int n_dirs, int n_mics,
+                                                       int n_bins, float* __restrict__ are, float* __restrict__ aim)
+{
+    const size_t total = (size_t)n_bins * n_mics * n_dirs;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % n_dirs);
+        const int m = (int)((i / n_dirs) % n_mics);
+        const int k = (int)(i / ((size_t)n_dirs * n_mics));
+        const double ph = -2.0 * 3.14159265358979323846 * freq[k] * tau[(size_t)d * n_mics + m];
+        are[i] = (float)cos(ph);
+        aim[i] = (float)sin(ph);
+    }
+}
+
+// Per bin: R += delta * tr(R)/M * I;  R = L L^H (Cholesky, lower);  Linv = L^-1;  stores Linv TRANSPOSED planes
+// [bin][col][row] (the A-operand layout of the MVDR GEMM).  One workgroup per bin, everything in LDS (M <= 128).
+__global__ void __launch_bounds__(256) cholesky_inverse_kernel(const float* __restrict__ rre, const float* __restrict__ rim, int M, float loading,
+                                                               float* __restrict__ lire_t, float* __restrict__ liim_t, int* __restrict__ status)
+{
+    extern __shared__ float sm[];
+    float* Lr = sm;                 // M*M
+    float* Li = sm + M * M;         // M*M
+    __shared__ float s_diag, s_trace;
+    const int b = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+    const float* Rr = rre + (size_t)b * M * M;
+    const float* Ri = rim + (size_t)b * M * M;
+    for (int i = t; i < M * M; i += nt) { Lr[i] = Rr[i]; Li[i] = Ri[i]; }
+    __syncthreads();
+    if (t == 0) {
+        float tr = 0.0f;
+        for (int i = 0; i < M; ++i) tr += Lr[i * M + i];
+        s_trace = tr / (float)M;
+    }
+    __syncthreads();
+    if (t < M) { Lr[t * M + t] += loading * s_trace; Li[t * M + t] = 0.0f; }
+    __syncthreads();
+    // right-looking Cholesky on the lower triangle
+    for (int j = 0; j < M; ++j) {
+        if (t == 0) {
+            const float d = Lr[j * M + j];
+            if (!(d > 0.0f)) status[b] = j + 1;
+            s_diag = sqrtf(fmaxf(d, 1e-30f));
+            Lr[j * M + j] = s_diag;
+        }
+        __syncthreads();
+        const float inv = 1.0f / s_diag;
+        for (int i = j + 1 + t; i < M; i += nt) { Lr[i * M + j] *= inv; Li[i * M + j] *= inv; }
+        __syncthreads();
+        // trailing update: A[i][c] -= L[i][j] * conj(L[c][j]),  j < c <= i
+        const int rem = M - j - 1;
+        for (int e = t; e < rem * rem; e += nt) {
+            const int i = j + 1 + e / rem, c = j + 1 + e % rem;
+            if (c <= i) {
+                const float ar = Lr[i * M + j], ai = Li[i * M + j], br = Lr[c * M + j], bi = Li[c * M + j];
+                Lr[i * M + c] -= ar * br + ai * bi;
+                Li[i * M + c] -= ai * br - ar * bi;
+            }
+        }
+        __syncthreads();
+    }
+    // invert the lower-triangular L column by column: thread c solves L x = e_c (forward substitution), x overwrites nothing in L
+    float* Or = lire_t + (size_t)b * M * M;
+    float* Oi = liim_t + (size_t)b * M * M;
+    for (int c = t; c < M; c += nt) {
+        // x[i] = (delta_ic - sum_{p<i} L[i][p] x[p]) / L[i][i]; entries above the diagonal are zero
+        for (int i = 0; i < M; ++i) {
+            float xr = (i == c) ? 1.0f : 0.0f, xi = 0.0f;
+            if (i < c) { Or[(size_t)c * M + i] = 0.0f; Oi[(size_t)c * M + i] = 0.0f; continue; }
+            for (int p = c; p < i; ++p) {
+                const float lr = Lr[i * M + p], li = Li[i * M + p];
+                const float pr = Or[(size_t)c * M + p], pi = Oi[(size_t)c * M + p];   // x[p] (Linv[p][c]) stored at [c][p]
+                xr -= lr * pr - li * pi;
+                xi -= lr * pi + li * pr;
+            }
+            const float inv = 1.0f / Lr[i * M + i];
+            Or[(size_t)c * M + i] = xr * inv;   // Linv[i][c] at transposed position [c][i]
+            Oi[(size_t)c * M + i] = xi * inv;
+        }
+    }
+}
+
+template <int EPI>
+hipError_t run_gemm(const GemmArgs& g, hipStream_t stream)
+{
+    const dim3 grid((unsigned)((g.J + 127) / 128), (unsigned)(EPI == EPI_MVDR ? 1 : (g.I + 31) / 32), (unsigned)(EPI == EPI_STORE ? g.batch : 1));
+    hipLaunchKernelGGL(cgemm_kernel<EPI>, grid, dim3(256), 0, stream, g);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_fd_steering(const double* d_tau, const double* d_freq, int n_dirs, int n_mics, int n_bins, float* d_are, float* d_aim, hipStream_t stream)
+{
+    hipLaunchKernelGGL(steering_kernel, dim3(2048), dim3(256), 0, stream, d_tau, d_freq, n_dirs, n_mics, n_bins, d_are, d_aim);
+    return hipGetLastError();
+}
+
+hipError_t launch_fd_dft(const float* d_frames, const int32_t* d_mics, int m_total, int n_samples, int n_frames, int n_mics, int bin_lo, int n_bins,
+                         float* xre_mf, float* xim_mf, float* xre_fm, float* xim_fm, hipStream_t stream)
+{
+    hipLaunchKernelGGL(dft_kernel, dim3((unsigned)(n_frames * n_mics)), dim3(128), (size_t)3 * n_samples * sizeof(float), stream, d_frames, d_mics, m_total,
+                       n_samples, n_frames, n_mics, bin_lo, n_bins, xre_mf, xim_mf, xre_fm, xim_fm);
+    return hipGetLastError();
+}
+
+hipError_t launch_fd_das_power(const float* xre_mf, const float* xim_mf, const float* are, const float* aim, int n_frames, int n_mics, int n_dirs,
+                               int n_bins, float* d_power, hipStream_t stream)
+{
+    GemmArgs g{xre_mf, xim_mf, are, aim, d_power, nullptr, n_frames, n_dirs, n_mics, n_bins, 0, 1.0f};
+    return run_gemm<EPI_POWER>(g, stream);
+}
+
+hipError_t launch_fd_covariance(const float* xre_fm, const float* xim_fm, int n_frames, int n_mics, int n_bins, float* rre, float* rim, hipStream_t stream)
+{
+    // R[i][j] = (1/F) sum_f x[f][i] conj(x[f][j]):  A = X ([K=frames][I=mics]), B = conj(X) ([K=frames][J=mics])
+    GemmArgs g{xre_fm, xim_fm, xre_fm, xim_fm, rre, rim, n_mics, n_mics, n_frames, n_bins, 1, 1.0f / (float)n_frames};
+    return run_gemm<EPI_STORE>(g, stream);
+}
+
+hipError_t launch_fd_cholesky_inverse(const float* rre, const float* rim, int n_mics, int n_bins, float loading, float* lire_t, float* liim_t,
+                                      int* d_status, hipStream_t stream)
+{
+    const size_t lds = (size_t)2 * n_mics * n_mics * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cholesky_inverse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(cholesky_inverse_kernel, dim3((unsigned)n_bins), dim3(256), lds, stream, rre, rim, n_mics, loading, lire_t, liim_t, d_status);
+    return hipGetLastError();
+}
+
+hipError_t launch_fd_mvdr_power(const float* lire_t, const float* liim_t, const float* are, const float* aim, int n_mics, int n_dirs, int n_bins,
+                                float* d_power, hipStream_t stream)
+{
+    // y = Linv a:  A = Linv ([K=col][I=row], i.e. the transposed planes), B = a ([K=mic][J=dir]);  P[d] = sum_k 1 / ||y||^2
+    GemmArgs g{lire_t, liim_t, are, aim, d_power, nullptr, n_mics, n_dirs, n_mics, n_bins, 0, 1.0f};
+    return run_gemm<EPI_MVDR>(g, stream);
+}
+
+}  // namespace bf

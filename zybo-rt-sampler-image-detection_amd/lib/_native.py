@@ -85,6 +85,12 @@ _sig("bf_ingest_device", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_voi
 _sig("bf_heatmap_colorize_device", C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p)
 _sig("bf_heatmap_overlay_device", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p)
 _sig("bf_power_center_device", C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+_sig("bf_fd_steering_device", C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+_sig("bf_fd_dft_device", C.c_int, C.c_void_p, C.c_int, C.c_int, IP, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_sig("bf_fd_das_power_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+_sig("bf_fd_covariance_device", C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+_sig("bf_fd_cholesky_inverse_device", C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_sig("bf_fd_mvdr_power_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
 _sig("bf_get_lerp_tables", C.c_int, IP, FP, C.c_int)
 _sig("bf_get_hybrid_tables", C.c_int, IP, FP, C.c_int)
 _sig("bf_default_geometry", None, C.POINTER(Geometry))
