@@ -1,0 +1,95 @@
+"""Frequency-domain beamformers.
+
+CPU: the NumPy oracle against the golden vectors produced by importing the reference's realtime_scripts (bit-exact).
+GPU: the MFMA path against the golden vectors (phase-steer DAS) and against the builder-defined float64 oracle (MVDR).
+The reference computes in float64/complex128; the GPU path is float32 (exact-f32 MFMA), so the tolerance is relative to
+the map's peak: 2e-5 of the maximum per pixel (the maps are normalised by their maximum before display)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import util
+
+TOL_OF_PEAK = 2e-5
+
+
+def gold():
+    return np.load(util.GOLDEN + "/fft_backend.npz")
+
+
+def test_oracle_matches_reference_bit_exact():
+    import freq_np as F
+    g = gold()
+    t = F.tables()
+    assert np.array_equal(t["r_prime_all"], g["r_prime_all"]) and np.array_equal(t["freq"], g["freq"])
+    assert (t["bin_lo"], t["bin_hi"]) == (int(g["bin_lo"]), int(g["bin_hi"]))
+    assert hashlib.sha256(np.ascontiguousarray(t["phase_shift"]).tobytes()).hexdigest() == str(g["phase_shift_sha256"])
+    for k in ("f1", "f2", "f3"):
+        assert np.array_equal(F.das_power(g["in_" + k], t["phase_shift"], t["bin_lo"], t["bin_hi"]), g["power_" + k])
+        assert np.array_equal(F.das_heatmap(g["in_" + k], t["phase_shift"], t["bin_lo"], t["bin_hi"]), g["heatmap_" + k])
+    assert not g["heatmap_f3"].any()                      # quiet input: the reference blanks the map
+
+
+def _scene(t, ix, iy, n_frames, rng, M=64, N=256):
+    xs, ys = t["x_scan"][ix], t["y_scan"][iy]
+    r = np.sqrt(xs * xs + ys * ys + 1.0)
+    tau = (xs * t["r_prime_all"][0] + ys * t["r_prime_all"][1]) / r / 343.0
+    tt = np.arange(N) / 48828.0
+    return np.stack([sum(np.sin(2 * np.pi * f * (tt[:, None] + tau[None, :]) + rng.uniform(0, 6.28)) for f in (2500.0, 5200.0, 8100.0)) +
+                     0.3 * rng.standard_normal((N, M)) for _ in range(n_frames)])
+
+
+def test_mvdr_oracle_properties():
+    """Builder-defined MVDR: peak at the source, main lobe no wider than delay-and-sum on the same data."""
+    import freq_np as F
+    t = F.tables(res_x=9, res_y=7, arrays=1)
+    frames = _scene(t, 6, 2, 96, np.random.default_rng(3))
+    p = F.mvdr_power(frames, t["phase_shift"], t["bin_lo"], t["bin_hi"])
+    assert np.unravel_index(np.argmax(p), p.shape) == (6, 2)
+    d = sum(F.das_power(fr, t["phase_shift"], t["bin_lo"], t["bin_hi"]) for fr in frames)
+    assert (p / p.max() > 0.5).sum() <= (d / d.max() > 0.5).sum()
+
+
+@pytest.mark.gpu
+def test_gpu_phase_steer_matches_reference(native):
+    import torch
+    from realtime_scripts import beam_forming_algorithm as B
+    g = gold()
+    for k in ("f1", "f2", "f3"):
+        got = B.main(g["in_" + k])
+        want = g["heatmap_" + k]
+        assert got.shape == want.shape
+        assert np.max(np.abs(got - want)) <= TOL_OF_PEAK * max(1.0, float(want.max())), k
+    fb = B._default
+    frames = np.zeros((3, 256, 256), dtype=np.float32)
+    for i, k in enumerate(("f1", "f2", "f3")):
+        frames[i, fb.active] = g["in_" + k].T
+    p = fb.das_power(torch.from_numpy(frames).cuda()).double().cpu().numpy()
+    for i, k in enumerate(("f1", "f2", "f3")):
+        want = g["power_" + k].ravel()
+        assert np.max(np.abs(p[i] - want)) <= TOL_OF_PEAK * want.max(), k
+    assert np.argmax(p[1]) == np.argmax(g["power_f2"])
+
+
+@pytest.mark.gpu
+def test_gpu_mvdr_matches_float64_oracle(native):
+    import torch
+    import freq_np as F
+    from realtime_scripts import beam_forming_algorithm as B, config as C
+    old = (C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y)
+    C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y = 64, 1, 31, 23
+    try:
+        fb = B.FrequencyBeamformer()
+        t = F.tables(res_x=31, res_y=23, arrays=1)
+        frames = _scene(t, 20, 7, 128, np.random.default_rng(5)).astype(np.float32)
+        want = F.mvdr_power(frames.astype(np.float64), t["phase_shift"], t["bin_lo"], t["bin_hi"], loading=1e-2).ravel()
+        d_frames = torch.from_numpy(np.ascontiguousarray(frames.transpose(0, 2, 1))).cuda()      # [F, M, N] mic-major
+        got = fb.mvdr_power(d_frames, loading=1e-2).double().cpu().numpy()
+        assert np.argmax(got) == np.argmax(want) == 20 * 23 + 7
+        assert np.max(np.abs(got - want) / want) <= 2e-4          # conditioning of R^-1 in float32 (delta = 1e-2)
+        dwant = np.stack([F.das_power(fr, t["phase_shift"], t["bin_lo"], t["bin_hi"]).ravel() for fr in frames[:8].astype(np.float64)])
+        dgot = fb.das_power(d_frames[:8].contiguous()).double().cpu().numpy()
+        assert np.max(np.abs(dgot - dwant)) <= TOL_OF_PEAK * dwant.max()
+    finally:
+        C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y = old
