@@ -72,7 +72,8 @@ def das_heatmap(signal, phase_shift, bin_lo, bin_hi, threshold=0.2):
 
 def mvdr_power(frames, phase_shift, bin_lo, bin_hi, loading=1e-2):
     """Builder-defined MVDR (Capon) map.  frames float [F, N, M] (F windows of the same scene).
-    Per bin k: R = (1/F) sum_f x x^H + loading * tr(R)/M * I;  P[x, y] = sum_k 1 / real(a^H R^-1 a),  a = phase_shift[k, :, x, y]."""
+    Per bin k: R = (1/F) sum_f x x^H + loading * tr(R)/M * I;  P[x, y] = sum_k 1 / real(v^H R^-1 v),  v = conj(phase_shift[k, :, x, y]).
+    (The reference's delay-and-sum output is sum_m phase_shift_m x_m = v^H x, so v is the steering vector in the usual w^H x sense.)"""
     F, N, M = frames.shape
     Xf = np.fft.rfft(frames, axis=1)[:, bin_lo:bin_hi, :]          # [F, K, M]
     K = Xf.shape[1]
@@ -81,7 +82,7 @@ def mvdr_power(frames, phase_shift, bin_lo, bin_hi, loading=1e-2):
         x = Xf[:, k, :]                                            # [F, M]
         R = (x.T @ x.conj()) / F
         R = R + loading * (np.trace(R).real / M) * np.eye(M)
-        a = phase_shift[k].reshape(M, -1)                          # [M, D]
+        a = np.conj(phase_shift[k].reshape(M, -1))                 # [M, D]
         Ria = np.linalg.solve(R, a)
         out += (1.0 / np.real(np.sum(a.conj() * Ria, axis=0))).reshape(out.shape)
     return out

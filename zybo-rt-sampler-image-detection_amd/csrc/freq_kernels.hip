@@ -4,15 +4,15 @@
 // calc_phase_shift_cartesian.py:37-50 (NumPy, complex128):
 //     X = rfft(signal, axis=0)[bins];  B[k, d] = sum_m X[k, m] * exp(-j 2 pi f_k tau[d, m]);  P[d] = sum_k |B[k, d]|^2
 // MVDR (BASELINE.json config 3) has NO counterpart in the reference; it is defined here as
-//     R_k = (1/F) sum_frames x x^H + delta * tr(R_k)/M * I;   P[d] = sum_k 1 / (a_{k,d}^H R_k^{-1} a_{k,d})
-// with the same steering vectors a_{k,d}[m] = exp(-j 2 pi f_k tau[d, m]).
+//     R_k = (1/F) sum_frames x x^H + delta * tr(R_k)/M * I;   P[d] = sum_k 1 / (v_{k,d}^H R_k^{-1} v_{k,d})
+// with v = conj(a), a_{k,d}[m] = exp(-j 2 pi f_k tau[d, m]) the reference's phase shifts (its beam is sum_m a_m x_m = v^H x).
 //
 // This is the only GEMM-shaped work in the repository, so it is the only place MFMA is used: one complex-GEMM
 // kernel built on v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit-wise an fmaf chain, no reduced precision),
 // specialised by its epilogue:
 //     EPI_POWER   C = X_k^T A_k      (frames x dirs)  ->  P[f, d] += |C|^2 over the bins      (phase-steer DAS)
 //     EPI_STORE   C = X_k X_k^H / F  (mics x mics)    ->  R_k                                  (covariance)
-//     EPI_MVDR    C = L_k^-1 A_k     (mics x dirs)    ->  P[d] += 1 / sum_m |C[m, d]|^2         (MVDR quadratic form)
+//     EPI_MVDR    C = L_k^-1 conj(A_k) (mics x dirs)  ->  P[d] += 1 / sum_m |C[m, d]|^2         (MVDR quadratic form)
 // Operands are stored as separate re / im planes, K-major with the tile index contiguous ([batch][k][i]), so that the
 // MFMA lane map (A: lane l holds A[i = l & 31][k = l >> 5]; B: B[k = l >> 5][j = l & 31]) reads 128-byte rows.
 // A complex product is four real MFMAs; conj(B) is a sign flip of the loaded imaginary part.
@@ -297,7 +297,8 @@ hipError_t launch_fd_mvdr_power(const float* lire_t, const float* liim_t, const 
                                 float* d_power, hipStream_t stream)
 {
     // y = Linv a:  A = Linv ([K=col][I=row], i.e. the transposed planes), B = a ([K=mic][J=dir]);  P[d] = sum_k 1 / ||y||^2
-    GemmArgs g{lire_t, liim_t, are, aim, d_power, nullptr, n_mics, n_dirs, n_mics, n_bins, 0, 1.0f};
+    // the steering vector in the w^H x sense is v = conj(a) (the delay-and-sum output is sum_m a_m x_m = v^H x)
+    GemmArgs g{lire_t, liim_t, are, aim, d_power, nullptr, n_mics, n_dirs, n_mics, n_bins, 1, 1.0f};
     return run_gemm<EPI_MVDR>(g, stream);
 }
 
