@@ -170,6 +170,20 @@ int bf_fd_cholesky_inverse_device(const float *d_rre, const float *d_rim, int n_
 int bf_fd_mvdr_power_device(const float *d_lire_t, const float *d_liim_t, const float *d_are, const float *d_aim, int n_mics, int n_dirs,
                             int n_bins, float *d_power, void *stream);
 
+/* ---- detector post-processing (device pointers, enqueue only).  The reference obtains boxes from
+ * ultralytics.YOLO(...).predict (image-detection/src/yolo_smooth_tracking.py:9-23); these are the published YOLOv5 head
+ * decode and non-maximum suppression it performs internally.
+ *   bf_yolo_decode_device: raw[l] = head output of level l, [batch][3*(5+nc)][h[l]][w[l]] (float32, or float16 when is_half);
+ *       anchors float32 [3][3][2] (pixels, HOST pointer); writes xyxy boxes [batch][T][4], scores [batch][T] (obj*cls, or -1
+ *       when under conf_thres) and class ids [batch][T], T = 3 * sum(h*w).
+ *   bf_nms_device: boxes / scores / cls of the K best candidates per image, already sorted by descending score, counts[b] valid
+ *       entries; d_mask workspace uint64 [batch][K][ceil(K/64)]; writes up to max_det rows [x1,y1,x2,y2,score,cls] per image
+ *       and the number kept.  K <= 4096. */
+int bf_yolo_decode_device(const void *const raw[3], const int h[3], const int w[3], const int strides[3], const float *anchors, int batch, int nc,
+                          int is_half, float conf_thres, float *d_boxes, float *d_scores, int *d_cls, void *stream);
+int bf_nms_device(const float *d_boxes, const float *d_scores, const int *d_cls, const int *d_counts, int batch, int k, float iou_thres, int max_det,
+                  unsigned long long *d_mask, float *d_out, int *d_out_count, void *stream);
+
 /* Launch geometry the planner picks for a call like the above (no GPU needed): out[0..9] = nc, lead,
  * row_stride, mic_chunk, n_chunks, waves, dpw, tile_dirs, n_tiles, lds_bytes.  Returns 0 or -1. */
 int bf_plan_das(int algo, int n, int frames, int dir_begin, int dir_end, int max_whole, int n_cus, long long out[10]);

@@ -894,6 +894,23 @@ int bf_fd_mvdr_power_device(const float* d_lire_t, const float* d_liim_t, const 
     return HIP_OK(bf::launch_fd_mvdr_power(d_lire_t, d_liim_t, d_are, d_aim, n_mics, n_dirs, n_bins, d_power, st)) ? 0 : -1;
 }
 
+// ---------------------------------------------------------------- detector post-processing
+
+int bf_yolo_decode_device(const void* const raw[3], const int h[3], const int w[3], const int strides[3], const float* anchors, int batch, int nc,
+                          int is_half, float conf_thres, float* d_boxes, float* d_scores, int* d_cls, void* stream)
+{
+    FD_ENTER(raw && raw[0] && raw[1] && raw[2] && h && w && strides && anchors && d_boxes && d_scores && d_cls && batch > 0 && nc > 0, "bf_yolo_decode_device")
+    return HIP_OK(bf::launch_yolo_decode(raw, h, w, strides, anchors, batch, nc, is_half, conf_thres, d_boxes, d_scores, d_cls, st)) ? 0 : -1;
+}
+
+int bf_nms_device(const float* d_boxes, const float* d_scores, const int* d_cls, const int* d_counts, int batch, int k, float iou_thres, int max_det,
+                  unsigned long long* d_mask, float* d_out, int* d_out_count, void* stream)
+{
+    FD_ENTER(d_boxes && d_scores && d_cls && d_counts && d_mask && d_out && d_out_count && batch > 0 && k > 0 && max_det > 0, "bf_nms_device")
+    if (k > 4096) { set_error("bf_nms_device: k = %d candidates; at most 4096", k); return -1; }
+    return HIP_OK(bf::launch_nms(d_boxes, d_scores, d_cls, d_counts, batch, k, iou_thres, max_det, d_mask, d_out, d_out_count, st)) ? 0 : -1;
+}
+
 int bf_plan_das(int algo, int n, int frames, int dir_begin, int dir_end, int max_whole, int n_cus, long long out[10])
 {
     State& s = S();

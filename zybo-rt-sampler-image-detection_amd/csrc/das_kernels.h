@@ -99,4 +99,10 @@ hipError_t launch_fd_cholesky_inverse(const float* rre, const float* rim, int n_
 hipError_t launch_fd_mvdr_power(const float* lire_t, const float* liim_t, const float* are, const float* aim, int n_mics, int n_dirs, int n_bins,
                                 float* d_power, hipStream_t stream);
 
+// detector post-processing (nms_kernels.hip): YOLOv5 head decode + confidence filter, greedy NMS over score-sorted candidates
+hipError_t launch_yolo_decode(const void* const raw[3], const int hs[3], const int ws[3], const int strides[3], const float* anchors,
+                              int batch, int nc, int is_half, float conf_thres, float* d_boxes, float* d_scores, int* d_cls, hipStream_t stream);
+hipError_t launch_nms(const float* d_boxes, const float* d_scores, const int* d_cls, const int* d_counts, int batch, int K, float iou_thres,
+                      int max_det, unsigned long long* d_mask, float* d_out, int* d_out_count, hipStream_t stream);
+
 }  // namespace bf

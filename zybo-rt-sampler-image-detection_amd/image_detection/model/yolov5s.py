@@ -1,0 +1,121 @@
+"""YOLOv5s-shaped detector (PyTorch-ROCm) -- the network behind the reference's `ultralytics.YOLO(best.pt)`.
+
+The reference ships neither the architecture nor the weights (`image-detection/model/*` is git-ignored and listed in
+.MISSING_LARGE_BLOBS; `ultralytics` is an unpinned third-party package), so this is the published YOLOv5s v6.x graph
+(depth 0.33, width 0.50: 6x6/2 stem, C3 stages 64-128-256-512, SPPF, PAN head, three detect levels at strides 8/16/32,
+anchors of the COCO release) with seeded random weights and `nc` classes (1 in the reference's use: drones).
+Convolutions run through MIOpen on the matrix cores (fp16, channels_last, BatchNorm folded); the head decode and the
+NMS are the hand-written HIP kernels of csrc/nms_kernels.hip."""
+import torch
+import torch.nn as nn
+
+ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]
+STRIDES = [8, 16, 32]
+
+
+class Conv(nn.Module):
+    def __init__(self, c1, c2, k=1, s=1, p=None):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, c2, k, s, k // 2 if p is None else p, bias=False)
+        self.bn = nn.BatchNorm2d(c2, eps=1e-3, momentum=0.03)
+        self.act = nn.SiLU(inplace=True)
+
+    def forward(self, x):
+        return self.act(self.bn(self.conv(x)))
+
+    def fuse(self):
+        """Fold the BatchNorm into the convolution (inference)."""
+        w = self.bn.weight / torch.sqrt(self.bn.running_var + self.bn.eps)
+        fused = nn.Conv2d(self.conv.in_channels, self.conv.out_channels, self.conv.kernel_size, self.conv.stride, self.conv.padding, bias=True)
+        fused.weight.data = (self.conv.weight * w.view(-1, 1, 1, 1)).detach()
+        fused.bias.data = (self.bn.bias - self.bn.running_mean * w).detach()
+        self.conv, self.bn = fused, nn.Identity()
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, c1, c2, shortcut=True):
+        super().__init__()
+        self.cv1, self.cv2 = Conv(c1, c2, 1), Conv(c2, c2, 3)
+        self.add = shortcut and c1 == c2
+
+    def forward(self, x):
+        y = self.cv2(self.cv1(x))
+        return x + y if self.add else y
+
+
+class C3(nn.Module):
+    def __init__(self, c1, c2, n=1, shortcut=True):
+        super().__init__()
+        c_ = c2 // 2
+        self.cv1, self.cv2, self.cv3 = Conv(c1, c_, 1), Conv(c1, c_, 1), Conv(2 * c_, c2, 1)
+        self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut) for _ in range(n)))
+
+    def forward(self, x):
+        return self.cv3(torch.cat((self.m(self.cv1(x)), self.cv2(x)), 1))
+
+
+class SPPF(nn.Module):
+    def __init__(self, c1, c2, k=5):
+        super().__init__()
+        c_ = c1 // 2
+        self.cv1, self.cv2 = Conv(c1, c_, 1), Conv(c_ * 4, c2, 1)
+        self.m = nn.MaxPool2d(k, 1, k // 2)
+
+    def forward(self, x):
+        x = self.cv1(x)
+        y1 = self.m(x)
+        y2 = self.m(y1)
+        return self.cv2(torch.cat((x, y1, y2, self.m(y2)), 1))
+
+
+class YOLOv5s(nn.Module):
+    """forward(x [B, 3, H, W] in [0, 1]) -> the three raw head maps [B, 3*(5+nc), H/8, W/8], [.., H/16, ..], [.., H/32, ..]."""
+
+    def __init__(self, nc=1):
+        super().__init__()
+        self.nc, self.no = nc, nc + 5
+        self.b0, self.b1, self.b2 = Conv(3, 32, 6, 2, 2), Conv(32, 64, 3, 2), C3(64, 64, 1)
+        self.b3, self.b4 = Conv(64, 128, 3, 2), C3(128, 128, 2)
+        self.b5, self.b6 = Conv(128, 256, 3, 2), C3(256, 256, 3)
+        self.b7, self.b8, self.b9 = Conv(256, 512, 3, 2), C3(512, 512, 1), SPPF(512, 512)
+        self.h10, self.h13 = Conv(512, 256, 1), C3(512, 256, 1, False)
+        self.h14, self.h17 = Conv(256, 128, 1), C3(256, 128, 1, False)
+        self.h18, self.h20 = Conv(128, 128, 3, 2), C3(256, 256, 1, False)
+        self.h21, self.h23 = Conv(256, 256, 3, 2), C3(512, 512, 1, False)
+        self.up = nn.Upsample(scale_factor=2, mode="nearest")
+        self.detect = nn.ModuleList(nn.Conv2d(c, 3 * self.no, 1) for c in (128, 256, 512))
+
+    def forward(self, x):
+        p3 = self.b4(self.b3(self.b2(self.b1(self.b0(x)))))
+        p4 = self.b6(self.b5(p3))
+        p5 = self.b9(self.b8(self.b7(p4)))
+        t10 = self.h10(p5)
+        t14 = self.h14(self.h13(torch.cat((self.up(t10), p4), 1)))
+        o3 = self.h17(torch.cat((self.up(t14), p3), 1))
+        o4 = self.h20(torch.cat((self.h18(o3), t14), 1))
+        o5 = self.h23(torch.cat((self.h21(o4), t10), 1))
+        return [d(o) for d, o in zip(self.detect, (o3, o4, o5))]
+
+    def fuse(self):
+        for m in self.modules():
+            if isinstance(m, Conv) and isinstance(m.bn, nn.BatchNorm2d):
+                m.fuse()
+        return self
+
+
+def build(nc=1, seed=0, device="cuda", half=True):
+    """Seeded random-init network, inference mode, BatchNorm folded, fp16 channels_last on the GPU."""
+    torch.manual_seed(seed)
+    net = YOLOv5s(nc)
+    for m in net.modules():                      # give BatchNorm non-trivial statistics so that folding is exercised
+        if isinstance(m, nn.BatchNorm2d):
+            m.running_mean.uniform_(-0.1, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.uniform_(-0.1, 0.1)
+    for d, s in zip(net.detect, STRIDES):        # the release's bias initialisation: ~8 objects per 640 px image
+        b = d.bias.view(3, -1)
+        b.data[:, 4] += float(torch.log(torch.tensor(8 / (640 / s) ** 2)))
+        b.data[:, 5:] += float(torch.log(torch.tensor(0.6 / (nc - 0.99999))))
+    net.eval().fuse()
+    net = net.to(device)
+    if half:
+        net = net.half()
+    return net.to(memory_format=torch.channels_last)

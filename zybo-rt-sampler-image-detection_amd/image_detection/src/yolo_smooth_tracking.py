@@ -1,0 +1,103 @@
+"""Mirror of the detection caller of the reference (image-detection/src/yolo_smooth_tracking.py): `yolo_model(path)
+.get_detections(frame, conf_threshold)` -> [[x1, y1, x2, y2, conf], ...] and `compute_iou`, with the network forward in
+PyTorch-ROCm and the head decode + NMS in the HIP kernels of csrc/nms_kernels.hip.
+
+`model_path` may name a state_dict saved from `image_detection.model.yolov5s.YOLOv5s`; with None (the reference's
+weights are not in its repository) a seeded random-init network is used.  SORT tracking (sort/sort.py, GPL, CPU) and the
+OpenCV drawing of `process_video_track_boxes_only` stay with the reference; `split_detections` is its banding logic."""
+import ctypes as C
+
+import numpy as np
+
+from lib import _native as nat
+from ..model import yolov5s
+
+CONF_HIGH, CONF_LOW = 0.5, 0.1          # yolo_smooth_tracking.py:278-279
+IOU_THRES, MAX_DET, MAX_NMS = 0.45, 300, 1024
+
+
+class Detector:
+    """Batched device-resident detector: uint8/float frames already on the GPU in, [B, MAX_DET, 6] boxes + counts out."""
+
+    def __init__(self, model_path=None, nc=1, seed=0, device="cuda", half=True):
+        import torch
+        if not torch.cuda.is_available():
+            raise nat.BeamformerError("no usable HIP device; the detector has no CPU path")
+        self.torch, self.device, self.half, self.nc = torch, device, half, nc
+        self.net = yolov5s.build(nc, seed, device, half)
+        if model_path is not None:
+            self.net.load_state_dict(torch.load(model_path, map_location=device))
+        self.anchors = np.ascontiguousarray(np.asarray(yolov5s.ANCHORS, dtype=np.float32).reshape(3, 3, 2))
+
+    def preprocess(self, frames_u8):
+        """uint8 [B, H, W, 3] (BGR as OpenCV delivers it, main.pyx:632) -> network input [B, 3, H, W] RGB in [0, 1], channels_last."""
+        t = self.torch
+        x = frames_u8.flip(-1).permute(0, 3, 1, 2)
+        x = (x.half() if self.half else x.float()) / 255
+        return x.contiguous(memory_format=t.channels_last)
+
+    def raw(self, x):
+        with self.torch.no_grad():
+            return [o.contiguous() for o in self.net(x)]
+
+    def postprocess(self, raw, conf_thres=CONF_LOW, iou_thres=IOU_THRES, max_det=MAX_DET):
+        """Head maps -> (boxes float32 [B, max_det, 6] = x1, y1, x2, y2, conf, cls;  counts int32 [B]) on the device."""
+        t = self.torch
+        B = raw[0].shape[0]
+        hs = (C.c_int * 3)(*[int(r.shape[2]) for r in raw]); ws = (C.c_int * 3)(*[int(r.shape[3]) for r in raw])
+        st = (C.c_int * 3)(*yolov5s.STRIDES)
+        ptrs = (C.c_void_p * 3)(*[r.data_ptr() for r in raw])
+        T = 3 * sum(int(r.shape[2]) * int(r.shape[3]) for r in raw)
+        boxes = t.empty((B, T, 4), dtype=t.float32, device=self.device)
+        scores = t.empty((B, T), dtype=t.float32, device=self.device)
+        cls = t.empty((B, T), dtype=t.int32, device=self.device)
+        s = t.cuda.current_stream().cuda_stream
+        is_half = 1 if raw[0].dtype == t.float16 else 0
+        if nat.lib.bf_yolo_decode_device(ptrs, hs, ws, st, nat.fptr(self.anchors), B, self.nc, is_half, conf_thres, boxes.data_ptr(),
+                                         scores.data_ptr(), cls.data_ptr(), s) != 0:
+            nat.check()
+        K = min(MAX_NMS, T)
+        top, idx = t.topk(scores, K, dim=1)                                 # library sort: candidate order for the greedy pass
+        counts = (top > 0).sum(dim=1).to(t.int32)
+        cb = t.gather(boxes, 1, idx.unsqueeze(-1).expand(-1, -1, 4)).contiguous()
+        cc = t.gather(cls, 1, idx).contiguous()
+        top = top.contiguous()
+        mask = t.empty((B, K, (K + 63) // 64), dtype=t.int64, device=self.device)
+        out = t.zeros((B, max_det, 6), dtype=t.float32, device=self.device)
+        n_out = t.zeros((B,), dtype=t.int32, device=self.device)
+        if nat.lib.bf_nms_device(cb.data_ptr(), top.data_ptr(), cc.data_ptr(), counts.data_ptr(), B, K, iou_thres, max_det, mask.data_ptr(),
+                                 out.data_ptr(), n_out.data_ptr(), s) != 0:
+            nat.check()
+        return out, n_out
+
+    def detect(self, frames_u8, conf_thres=CONF_LOW):
+        return self.postprocess(self.raw(self.preprocess(frames_u8)), conf_thres)
+
+
+class yolo_model:
+    """yolo_smooth_tracking.py:9-23"""
+
+    def __init__(self, model_path=None):
+        self.model = Detector(model_path)
+
+    def get_detections(self, frame, conf_threshold=0.0):
+        """frame: uint8 [H, W, 3] BGR (H, W multiples of 32) -> [[x1, y1, x2, y2, conf], ...] with conf >= conf_threshold."""
+        t = self.model.torch
+        f = t.from_numpy(np.ascontiguousarray(frame)).to(self.model.device).unsqueeze(0)
+        out, n = self.model.detect(f, conf_thres=max(1e-3, min(conf_threshold, 0.25)) if conf_threshold > 0 else 0.25)
+        out, n = out[0].cpu().numpy(), int(n[0].item())
+        return [[*map(float, out[i, :4]), float(out[i, 4])] for i in range(n) if out[i, 4] >= conf_threshold]
+
+
+def compute_iou(box1, box2):
+    """yolo_smooth_tracking.py:26-37"""
+    x1, y1, x2, y2 = box1
+    x1g, y1g, x2g, y2g = box2
+    inter = max(0, min(x2, x2g) - max(x1, x1g)) * max(0, min(y2, y2g) - max(y1, y1g))
+    union = (x2 - x1) * (y2 - y1) + (x2g - x1g) * (y2g - y1g) - inter
+    return inter / union if union > 0 else 0
+
+
+def split_detections(detections, confh=CONF_HIGH, confl=CONF_LOW):
+    """yolo_smooth_tracking.py:303-305: (valid, candidates) bands handed to the tracker."""
+    return [d for d in detections if d[4] > confh], [d for d in detections if confl < d[4] <= confh]
