@@ -1,0 +1,73 @@
+"""Detector (BASELINE.json config 4): HIP decode + NMS against the NumPy restatement, the network against its own fp32
+forward, and the reference-named caller surface.  Parity with the reference is unpinned (see oracle/detect_np.py)."""
+import numpy as np
+import pytest
+
+import util
+
+
+def test_oracle_nms_properties():
+    import detect_np as D
+    boxes = np.array([[0, 0, 10, 10], [1, 1, 11, 11], [20, 20, 30, 30], [0, 0, 10, 10.5]], dtype=np.float32)
+    scores = np.array([0.9, 0.8, 0.7, 0.6], dtype=np.float32)
+    assert D.nms(boxes, scores, 0.45, 300) == [0, 2]
+    assert D.nms(boxes, scores, 0.95, 300) == [0, 1, 2, 3]
+    assert D.nms(boxes, scores, 0.45, 1) == [0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("half", [False, True])
+def test_gpu_decode_and_nms_match_oracle(native, half):
+    import torch
+    import detect_np as D
+    from image_detection.model import yolov5s
+    from image_detection.src.yolo_smooth_tracking import Detector
+    det = Detector(half=half)
+    rng = np.random.default_rng(4)
+    B, nc = 2, 1
+    raw_np = [rng.normal(0, 1.5, (B, 3 * (5 + nc), 640 // s, 640 // s)).astype(np.float32) for s in yolov5s.STRIDES]
+    for r in raw_np:                                   # a few confident, clustered objects so that NMS has work to do
+        r[:, 4::6] -= 4.0
+    raw_np[0][:, 4, 10:14, 20:24] = 6.0; raw_np[1][:, 10, 5:7, 5:9] = 5.0; raw_np[2][0, 16, 3, 3] = 7.0
+    dt = torch.float16 if half else torch.float32
+    raw = [torch.from_numpy(r).cuda().to(dt) for r in raw_np]
+    raw_q = [r.float().cpu().numpy() for r in raw]     # what the kernel really reads
+    out, n = det.postprocess(raw, conf_thres=0.1, iou_thres=0.45, max_det=300)
+    out, n = out.cpu().numpy(), n.cpu().numpy()
+    boxes, scores, cls = D.decode(raw_q, yolov5s.ANCHORS, yolov5s.STRIDES, nc, 0.1)
+    for b in range(B):
+        order = np.argsort(-scores[b], kind="stable")[:1024]
+        keep = D.nms(boxes[b][order], scores[b][order], 0.45, 300)
+        want = np.concatenate([boxes[b][order][keep], scores[b][order][keep][:, None]], axis=1)
+        assert n[b] == len(keep) and n[b] > 3
+        got = out[b, : n[b], :5]
+        gi, wi = np.lexsort((got[:, 0], -got[:, 4])), np.lexsort((want[:, 0], -want[:, 4]))
+        assert np.allclose(got[gi], want[wi], rtol=2e-5, atol=2e-4)
+
+
+@pytest.mark.gpu
+def test_gpu_network_matches_its_fp32_forward(native):
+    """fp16 channels_last inference vs the same seeded network in fp32: head logits agree to fp16 accuracy."""
+    import torch
+    from image_detection.model import yolov5s
+    x = torch.rand((2, 3, 640, 640), device="cuda")
+    ref = yolov5s.build(half=False)(x)
+    got = yolov5s.build(half=True)(x.half().contiguous(memory_format=torch.channels_last))
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape
+        err = (a.float() - b).abs().max().item() / b.abs().max().item()
+        assert err < 3e-2, err
+    n_params = sum(p.numel() for p in yolov5s.YOLOv5s(1).parameters())
+    assert 7.0e6 < n_params < 7.1e6                      # YOLOv5s with one class: 7.01 M parameters
+
+
+@pytest.mark.gpu
+def test_gpu_reference_named_caller(native):
+    from image_detection.src import yolo_smooth_tracking as Y
+    m = Y.yolo_model(None)
+    frame = np.random.default_rng(2).integers(0, 256, (640, 640, 3), dtype=np.uint8)
+    dets = m.get_detections(frame, conf_threshold=0.1)
+    assert isinstance(dets, list) and all(len(d) == 5 and d[4] >= 0.1 for d in dets)
+    valid, cand = Y.split_detections([[0, 0, 1, 1, 0.7], [0, 0, 1, 1, 0.3], [0, 0, 1, 1, 0.05]])
+    assert len(valid) == 1 and len(cand) == 1
+    assert abs(Y.compute_iou([0, 0, 10, 10], [5, 5, 15, 15]) - 25 / 175) < 1e-12
