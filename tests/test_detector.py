@@ -11,7 +11,7 @@ def test_oracle_nms_properties():
     boxes = np.array([[0, 0, 10, 10], [1, 1, 11, 11], [20, 20, 30, 30], [0, 0, 10, 10.5]], dtype=np.float32)
     scores = np.array([0.9, 0.8, 0.7, 0.6], dtype=np.float32)
     assert D.nms(boxes, scores, 0.45, 300) == [0, 2]
-    assert D.nms(boxes, scores, 0.95, 300) == [0, 1, 2, 3]
+    assert D.nms(boxes, scores, 0.96, 300) == [0, 1, 2, 3]          # IoU(box 3, box 0) = 100/105
     assert D.nms(boxes, scores, 0.45, 1) == [0]
 
 
