@@ -71,3 +71,38 @@ def test_gpu_reference_named_caller(native):
     valid, cand = Y.split_detections([[0, 0, 1, 1, 0.7], [0, 0, 1, 1, 0.3], [0, 0, 1, 1, 0.05]])
     assert len(valid) == 1 and len(cand) == 1
     assert abs(Y.compute_iou([0, 0, 10, 10], [5, 5, 15, 15]) - 25 / 175) < 1e-12
+
+
+@pytest.mark.gpu
+def test_gpu_fused_pipeline(native, oracle_lib):
+    """Config 4 end to end on the device: the power maps equal the standalone beamformer's, the overlaid frames equal the
+    standalone post-processing, the detector consumes them."""
+    import torch
+    import synth, visual_np as V
+    from lib import directions
+    from pipeline import FusedPipeline
+    c = util.configure("cfg2")
+    M, N, D, B = c["M"], c["N"], c["X"] * c["Y"], 4
+    pipe = FusedPipeline("lerp", 640)
+    delays = directions.calculate_delays()
+    pipe.load_tables(delays, np.arange(M))
+    windows = np.stack([synth.s3_plane_wave(delays[30 + 10 * i, 60 - 5 * i], N, seed=i) for i in range(B)])
+    cam = np.random.default_rng(8).integers(0, 256, (B, 640, 640, 3), dtype=np.uint8)
+    power, frames, boxes, counts = pipe.step(torch.from_numpy(windows).cuda(), torch.from_numpy(cam).cuda())
+    orc = oracle_lib.Oracle(N, c["X"], c["Y"], c["T"])
+    orc.load(1, np.float32(delays))
+    mics = np.arange(M, dtype=np.int32)
+    p = power.cpu().numpy()
+    for i in range(B):
+        assert p[i].tobytes() == orc.mimo_range(1, windows[i], mics, 0, D).tobytes()
+        assert np.argmax(p[i]) == (30 + 10 * i) * c["Y"] + 60 - 5 * i
+    # overlay chain reproduced from the kernel's own small images
+    st2 = __import__("visual").HeatmapStream(640, 640)
+    small, _ = st2.small_heatmaps(power)
+    prev = np.zeros((640, 640, 3), dtype=np.uint8)
+    f = frames.cpu().numpy()
+    for i in range(B):
+        res = V.add_weighted_u8(prev, 0.5, V.resize_linear_u8(small[i].cpu().numpy(), 640, 640), 0.5)
+        prev = res
+        assert np.array_equal(f[i], V.add_weighted_u8(cam[i], 0.9, res, 0.9))
+    assert boxes.shape == (B, 300, 6) and counts.shape == (B,)
