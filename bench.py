@@ -80,6 +80,55 @@ def cpu_baseline(workload, algo, budget_s=12.0):
             "sample": "%d frames of %s (%s, S2 noise), kernel only, tables preloaded, %.1f s" % (frames, workload, algo, el)}
 
 
+def timed(fn, torch, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def extras(torch, nat, delays, mics, dev):
+    """The other single-GPU BASELINE configs, measured after the headline run (each a few hundred ms):
+    config 3 MVDR (64 mics, 101x101), config 4 fused heat-map -> 640x640 overlay -> YOLOv5s detection, plus the
+    frequency-domain delay-and-sum and the detector alone.  Parity for MVDR / detector is unpinned."""
+    import synth
+    from pipeline import FusedPipeline
+    from realtime_scripts import beam_forming_algorithm as B, config as C
+    out = {}
+    M, N = 64, 256
+    # config 4
+    pipe = FusedPipeline("lerp", 640, dev)
+    pipe.load_tables(delays, mics)
+    Bf = 64
+    win = torch.from_numpy(synth.frame_batch(M, N, Bf)).to(dev)
+    cam = torch.randint(0, 256, (Bf, 640, 640, 3), dtype=torch.uint8, device=dev)
+    dt = timed(lambda: pipe.step(win, cam), torch, 10)
+    out["fused_heatmap_overlay_yolo"] = {"frames_per_s": Bf / dt, "batch": Bf, "image": "640x640x3 uint8", "detector": "YOLOv5s-shaped, fp16, random init, 1 class"}
+    x = pipe.detector.preprocess(cam)
+    dt = timed(lambda: pipe.detector.postprocess(pipe.detector.raw(x)), torch, 10)
+    out["yolo_only"] = {"detections_per_s": Bf / dt, "batch": Bf, "gflop_per_frame": 15.8}
+    # config 3 + frequency-domain DAS: same 64-mic array and 101x101 grid through the frequency-domain geometry
+    old = (C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y)
+    C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y = 64, 1, 101, 101
+    try:
+        fb = B.FrequencyBeamformer()
+        F = 190
+        frames = torch.from_numpy(synth.frame_batch(M, N, 64)).to(dev).repeat(3, 1, 1)[:F].contiguous()
+        dt = timed(lambda: fb.mvdr_power(frames, 1e-2), torch, 5)
+        flop = fb.K * (8.0 * M * M * F + 8.0 * M * M * fb.D)
+        out["mvdr"] = {"maps_per_s": 1.0 / dt, "frames_per_s": F / dt, "windows_per_map": F, "bins": fb.K, "ms_per_map": dt * 1e3,
+                       "mfma_tflops": flop / dt / 1e12, "mfma_peak_tflops_f32": 157.3}
+        dt = timed(lambda: fb.das_power(frames), torch, 5)
+        out["freq_domain_das"] = {"frames_per_s": F / dt, "ms_per_step": dt * 1e3, "mfma_tflops": fb.K * 8.0 * M * F * fb.D / dt / 1e12}
+    finally:
+        C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y = old
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +138,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
     ap.add_argument("--algo", default="lerp", choices=["pad", "lerp", "hybrid", "fir_vec", "fir_naive"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the MVDR / fused-detector side measurements")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -225,6 +275,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and args.algo in ("pad", "lerp", "hybrid"):
             line["cpu_baseline"] = cpu_baseline(args.workload, args.algo)
+        if world == 1 and not args.no_extras and args.workload == "cfg2":
+            try:
+                line["extra"] = extras(torch, nat, delays, mics, dev)
+            except Exception as e:      # side measurements must never take the headline line down
+                line["extra"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
