@@ -36,6 +36,25 @@ __global__ void __launch_bounds__(1024) probe(const int* __restrict__ tab, float
                 }
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) { a0 += v[u][0]; a1 += v[u][1]; a2 += v[u][2]; a3 += v[u][3]; }
+            } else if constexpr (MODE == 7 || MODE == 8 || MODE == 9) {
+                // product-like: table entries via v_readlane from a VGPR (7, 8) or s_load (9); packed adds (7) or plain adds (8, 9)
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                static f32x2 dummy;
+                int vtab = row[(m0 + lane) & 63];
+                float4 q[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const int pp = (MODE == 9) ? p[u] : __builtin_amdgcn_readlane(vtab, u);
+                    q[u] = reinterpret_cast<const float4*>(lds)[(m0 + u) * (rs >> 2) + 12 - (pp >> 2) + lane];
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    if constexpr (MODE == 7) {
+                        f32x2 x{a0, a1}, y{a2, a3};
+                        x += f32x2{q[u].x, q[u].y}; y += f32x2{q[u].z, q[u].w};
+                        a0 = x.x; a1 = x.y; a2 = y.x; a3 = y.y;
+                    } else { a0 += q[u].x; a1 += q[u].y; a2 += q[u].z; a3 += q[u].w; }
+                }
             } else if constexpr (MODE == 6) {
                 // quad + DPP + VGPR index mode: window W_u = v[64+8u : 71+8u] (W[4:7] = ds_read_b128 result, W[1:3] = previous lane's
                 // y,z,w via DPP); acc[t] += W[idx + t], idx = 4 - r in M0 (s_set_gpr_idx_on, SRC0 relative).  No branches.
@@ -177,7 +196,11 @@ int main()
             if (run<1, 16>("b128 unroll16", d_tab, d_out, waves, rmode)) return 1;
             if (run<2, 8>("b128+dpp unroll8", d_tab, d_out, waves, rmode)) return 1;
             if (run<3, 8>("b128+branch unroll8", d_tab, d_out, waves, rmode)) return 1;
-            if (run<6, 4>("b128+dpp+gpridx unroll4", d_tab, d_out, waves, rmode)) return 1;
+            if (run<7, 4>("b128 readlane pk_add u4", d_tab, d_out, waves, rmode, 136)) return 1;
+            if (run<8, 4>("b128 readlane add u4", d_tab, d_out, waves, rmode, 136)) return 1;
+            if (run<9, 4>("b128 sload add u4", d_tab, d_out, waves, rmode, 136)) return 1;
+            if (run<7, 8>("b128 readlane pk_add u8", d_tab, d_out, waves, rmode, 136)) return 1;
+            if (run<8, 8>("b128 readlane add u8", d_tab, d_out, waves, rmode, 136)) return 1;
             if (run<4, 4>("pairs b64x2 unroll4", d_tab, d_out, waves, rmode)) return 1;
             if (run<4, 8>("pairs b64x2 unroll8", d_tab, d_out, waves, rmode)) return 1;
             if (run<5, 4>("lerp pairs b64x4 unroll4", d_tab, d_out, waves, rmode)) return 1;

@@ -266,6 +266,8 @@ bool plan_or_error(bf::DasLaunch& L, bf::DasPlan* plan)
     L.force_layout = layout;             // A/B switch for tests and profiling (see DasPlan::layout)
     static const int debug = [] { const char* e = getenv("BF_DEBUG"); return e ? atoi(e) : 0; }();
     L.debug = debug;
+    static const int dpw = [] { const char* e = getenv("BF_DPW"); return e ? atoi(e) : 0; }();
+    L.force_dpw = dpw;
     const char* why = "";
     if (bf::plan_das(L, S().n_cus, plan, &why) != 0) { set_error("unsupported shape: %s", why); return false; }
     return true;

@@ -41,6 +41,7 @@ struct DasLaunch {
     int frames;
     int force_layout;        // tests/bench ($BF_LAYOUT): -1 = planner's choice, else 0 / 1 / 2 for pad and lerp at N <= 256
     int debug;               // profiling switches ($BF_DEBUG), 0 in production
+    int force_dpw;           // tests/bench ($BF_DPW): directions per wave of the shifted-copies kernel (4, 8, 16); 0 = planner's choice
 };
 
 // Plan chosen on the host for a launch (exposed so tests can check LDS sizing without a GPU).

@@ -21,6 +21,8 @@
 // see DESIGN.md for the byte/flop accounting.
 #include "das_kernels.h"
 
+#include <type_traits>
+
 namespace bf {
 
 namespace {
@@ -587,10 +589,8 @@ __global__ void __launch_bounds__(64) das_miso_kernel(BF_TABLE_PARAMS, const flo
 // Mic order and operation order are unchanged, so the maps stay bit-identical to the CPU reference.
 namespace copies {
 
-constexpr int kDpw = 4;          // directions per wave
 constexpr int kWaves = 16;       // waves per workgroup
-constexpr int kGroup = kDpw * kWaves;
-constexpr int kParkStride = 260; // floats per parked row (256 squares, direction id at [256], 16-byte aligned rows)
+constexpr int kParkStride = 260; // floats per parked row (256 squares, 16-byte aligned rows)
 
 __device__ __forceinline__ float dpp_prev(float x)   // lane-1's value, 0 in lane 0
 {
@@ -621,11 +621,19 @@ __device__ __forceinline__ void write_copies(float* row0, int rs, int lead, int 
     }
 }
 
-template <int ALGO>
-__global__ void __launch_bounds__(1024, 8) das_copies_kernel(BF_TABLE_PARAMS, KArgs a)   // 8 waves per SIMD = two workgroups per CU: at most 64 VGPRs
+// DPW = directions a wave carries across the mic chunks (a multiple of 4).  A chunk is consumed between two
+// workgroup barriers, so the work per chunk per wave -- DPW x mic_chunk steps -- has to dwarf the barrier + restage
+// cost: DPW = 4 with two 80 KiB workgroups per CU, or DPW = 8 / 16 with one workgroup owning the whole LDS.
+template <int ALGO, int DPW>
+__global__ void __launch_bounds__(1024, DPW == 4 ? 8 : 4) das_copies_kernel(BF_TABLE_PARAMS, KArgs a)
 {
     static_assert(ALGO == ALGO_PAD || ALGO == ALGO_LERP, "shifted-copies layout: pad and lerp");
+    static_assert(DPW % 4 == 0 && DPW <= 16, "directions per wave");
     constexpr int A = (ALGO == ALGO_LERP) ? 2 : 1;   // arrays per mic: s (and D)
+    constexpr int NQ = DPW / 4;                      // table registers: each holds 4 directions x 16 mics
+    constexpr int kPark = DPW >= 8 ? 8 : 4;          // rows parked (and chained) per wave at a time
+    constexpr int kGroup = DPW * kWaves;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -663,16 +671,19 @@ __global__ void __launch_bounds__(1024, 8) das_copies_kernel(BF_TABLE_PARAMS, KA
         }
         return v;
     };
-    // raw table entries of one chunk for this wave's 4 directions (lane = 16 j + m); nothing here touches the loaded
-    // values, so the loads stay in flight until table_offsets() is called a chunk later
-    auto fetch_table = [&](int g0, int m0, int mcc, int& vp, float& vh) {
+    // raw table entries of one chunk: register q, lane 16 j + m  <->  direction 4 q + j of this wave, staged mic m.
+    // Nothing here touches the loaded values, so the loads stay in flight until table_offsets() a chunk later.
+    auto fetch_table = [&](int g0, int m0, int mcc, int (&vp)[NQ], float (&vh)[NQ]) {
         const int j = lane >> 4, m = lane & 15;
-        const int d = g0 + wave * kDpw + j;
-        vp = 0; vh = 0.0f;
-        if (m < mcc && d < tile_end) {
-            const size_t idx = (size_t)d * M + m0 + m;
-            vp = whole[idx];
-            if constexpr (ALGO == ALGO_LERP) vh = frac[idx];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int d = g0 + wave * DPW + 4 * q + j;
+            vp[q] = 0; vh[q] = 0.0f;
+            if (m < mcc && d < tile_end) {
+                const size_t idx = (size_t)d * M + m0 + m;
+                vp[q] = whole[idx];
+                if constexpr (ALGO == ALGO_LERP) vh[q] = frac[idx];
+            }
         }
     };
     // delay -> LDS byte offset of the aligned quad row: copy (p & 3) of staged mic m, shifted back by p >> 2 quads
@@ -684,18 +695,16 @@ __global__ void __launch_bounds__(1024, 8) das_copies_kernel(BF_TABLE_PARAMS, KA
     };
 
     float4 staged = fetch(0, min(mc, M));
-    int vp_next; float vh_next;
+    int vp_next[NQ]; float vh_next[NQ];
     fetch_table(tile_begin, 0, min(mc, M), vp_next, vh_next);
 
-    // Plain f32 VALU instructions occupy a SIMD for 4 cycles per wave64 on gfx950; the packed forms (v_pk_add_f32,
-    // v_pk_fma_f32) do two lanes' worth of IEEE-identical work in the same slot, and the kernel is VALU-issue bound,
-    // so the accumulators are kept as two float2 register pairs matching the (x,y)/(z,w) halves of a quad read.
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-
     for (int g0 = tile_begin; g0 < tile_end; g0 += kGroup) {
-        f32x2 acc[kDpw][2];
+        // Plain f32 VALU instructions occupy a SIMD for 4 cycles per wave64 on gfx950; the packed forms (v_pk_add_f32,
+        // v_pk_fma_f32) do two lanes' worth of IEEE-identical work in the same slot, so the accumulators are kept as
+        // two float2 register pairs matching the (x,y)/(z,w) halves of a quad read.
+        f32x2 acc[DPW][2];
 #pragma unroll
-        for (int j = 0; j < kDpw; ++j) { acc[j][0] = f32x2{0.0f, 0.0f}; acc[j][1] = f32x2{0.0f, 0.0f}; }
+        for (int j = 0; j < DPW; ++j) { acc[j][0] = f32x2{0.0f, 0.0f}; acc[j][1] = f32x2{0.0f, 0.0f}; }
 
         for (int ch = 0; ch < a.n_chunks; ++ch) {
             const int m0 = ch * mc;
@@ -712,10 +721,10 @@ __global__ void __launch_bounds__(1024, 8) das_copies_kernel(BF_TABLE_PARAMS, KA
                 }
             }
             __syncthreads();
-            // request the next chunk (or the next group's first) while this one is consumed
-            const int ve = table_offsets(vp_next);
-            const float vh = vh_next;
-            {
+            int ve[NQ]; float vh[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { ve[q] = table_offsets(vp_next[q]); vh[q] = vh_next[q]; }
+            {   // request the next chunk (or the next group's first) while this one is consumed
                 int ng0 = g0, nch = ch + 1;
                 if (nch == a.n_chunks) { nch = 0; ng0 = g0 + kGroup; }
                 if (ng0 < tile_end) {
@@ -725,76 +734,74 @@ __global__ void __launch_bounds__(1024, 8) das_copies_kernel(BF_TABLE_PARAMS, KA
                 }
             }
             const char* lbase = reinterpret_cast<const char*>(lds) + 16 * lane;
-            auto step = [&](int j, int m) {
-                const int e = __builtin_amdgcn_readlane(ve, 16 * j + m);
-                const float4 S = *reinterpret_cast<const float4*>(lbase + e);
-                const f32x2 S01{S.x, S.y}, S23{S.z, S.w};
-                if constexpr (ALGO == ALGO_PAD) {
-                    // pad_and_sum.c:41-47   out[k] += s[k - p]
-                    acc[j][0] += S01; acc[j][1] += S23;
-                } else {
-                    // lerp_and_sum.c:50-56  out[k] += s[i] + h * (s[i+1] - s[i]),  i = k - p - 1
-                    const float h = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vh), 16 * j + m));
-                    const float4 Dq = *reinterpret_cast<const float4*>(lbase + e + 16 * rs);   // D copies sit 4 rows after the s copies
-                    const f32x2 h2{h, h}, D01{Dq.x, Dq.y}, D23{Dq.z, Dq.w};
-                    acc[j][0] += __builtin_elementwise_fma(h2, D01, S01);
-                    acc[j][1] += __builtin_elementwise_fma(h2, D23, S23);
+            // One batch = the 4 directions of table register q for staged mic m: all their LDS reads are issued before
+            // any result is consumed (written this way because the compiler otherwise reuses one destination register
+            // quad and waits for every read before issuing the next: one read in flight per wave).
+            auto batch = [&](auto qc, int m) {
+                constexpr int q = decltype(qc)::value;
+                float4 S[4], Dq[4];
+                float h[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = __builtin_amdgcn_readlane(ve[q], 16 * j + m);
+                    S[j] = *reinterpret_cast<const float4*>(lbase + e);
+                    if constexpr (ALGO == ALGO_LERP) {
+                        Dq[j] = *reinterpret_cast<const float4*>(lbase + e + 16 * rs);   // D copies sit 4 rows after the s copies
+                        h[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vh[q]), 16 * j + m));
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x2(&ac)[2] = acc[4 * q + j];
+                    const f32x2 S01{S[j].x, S[j].y}, S23{S[j].z, S[j].w};
+                    if constexpr (ALGO == ALGO_PAD) {
+                        // pad_and_sum.c:41-47   out[k] += s[k - p]
+                        ac[0] += S01; ac[1] += S23;
+                    } else {
+                        // lerp_and_sum.c:50-56  out[k] += s[i] + h * (s[i+1] - s[i]),  i = k - p - 1
+                        const f32x2 h2{h[j], h[j]}, D01{Dq[j].x, Dq[j].y}, D23{Dq[j].z, Dq[j].w};
+                        ac[0] += __builtin_elementwise_fma(h2, D01, S01);
+                        ac[1] += __builtin_elementwise_fma(h2, D23, S23);
+                    }
                 }
             };
-            // 2 mics x 4 directions (pad) or 1 mic x 4 directions (lerp) of independent reads per block keeps the
-            // kernel inside the 64-VGPR budget that lets two workgroups share a CU
-            if constexpr (ALGO == ALGO_PAD) {
-                int m = 0;
-                for (; m + 2 <= mcc; m += 2) {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int j = 0; j < kDpw; ++j) step(j, m + u);
-                }
-                for (; m < mcc; ++m) {
-#pragma unroll
-                    for (int j = 0; j < kDpw; ++j) step(j, m);
-                }
-            } else {
-                // lerp holds two quads per read pair: two directions at a time (16 VGPRs of reads in flight)
-                for (int m = 0; m < mcc; ++m) {
-                    step(0, m); step(1, m);
-                    __builtin_amdgcn_sched_barrier(0);
-                    step(2, m); step(3, m);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
+            auto mic_steps = [&](int m) {
+                batch(std::integral_constant<int, 0>{}, m);
+                if constexpr (NQ > 1) batch(std::integral_constant<int, 1>{}, m);
+                if constexpr (NQ > 2) { batch(std::integral_constant<int, 2>{}, m); batch(std::integral_constant<int, 3>{}, m); }
+            };
+            for (int m = 0; m < mcc; ++m) mic_steps(m);
         }
 
-        // ---- k-ordered mean power of this wave's 4 directions (rows alias the chunk buffer)
+        // ---- k-ordered mean power of this wave's directions (rows alias the chunk buffer), kPark at a time
         __syncthreads();
-        float* rows = lds + wave * kDpw * kParkStride;
+        float* rows = lds + wave * kPark * kParkStride;
 #pragma unroll
-        for (int j = 0; j < kDpw; ++j) {
-            float4 sq;
-            {
-                const float o0 = a.n_is_pow2 ? acc[j][0].x * a.inv_n : acc[j][0].x / (float)M;
-                const float o1 = a.n_is_pow2 ? acc[j][0].y * a.inv_n : acc[j][0].y / (float)M;
-                const float o2 = a.n_is_pow2 ? acc[j][1].x * a.inv_n : acc[j][1].x / (float)M;
-                const float o3 = a.n_is_pow2 ? acc[j][1].y * a.inv_n : acc[j][1].y / (float)M;
-                sq = make_float4(o0 * o0, o1 * o1, o2 * o2, o3 * o3);
+        for (int r0 = 0; r0 < DPW; r0 += kPark) {
+#pragma unroll
+            for (int j = 0; j < kPark; ++j) {
+                const f32x2 a0 = acc[r0 + j][0], a1 = acc[r0 + j][1];
+                const float o0 = a.n_is_pow2 ? a0.x * a.inv_n : a0.x / (float)M;
+                const float o1 = a.n_is_pow2 ? a0.y * a.inv_n : a0.y / (float)M;
+                const float o2 = a.n_is_pow2 ? a1.x * a.inv_n : a1.x / (float)M;
+                const float o3 = a.n_is_pow2 ? a1.y * a.inv_n : a1.y / (float)M;
+                reinterpret_cast<float4*>(rows + j * kParkStride)[lane] = make_float4(o0 * o0, o1 * o1, o2 * o2, o3 * o3);
             }
-            reinterpret_cast<float4*>(rows + j * kParkStride)[lane] = sq;
-        }
-        if (lane < kDpw) {
-            const int d = g0 + wave * kDpw + lane;
-            if (d < tile_end) {
-                const float* row = rows + lane * kParkStride;
-                const float4* row4 = reinterpret_cast<const float4*>(row);
-                float sum = 0.0f;
-                int k = 0;
+            if (lane < kPark) {
+                const int d = g0 + wave * DPW + r0 + lane;
+                if (d < tile_end) {
+                    const float* row = rows + lane * kParkStride;
+                    const float4* row4 = reinterpret_cast<const float4*>(row);
+                    float sum = 0.0f;
+                    int k = 0;
 #pragma unroll 4
-                for (; k + 4 <= N; k += 4) {
-                    const float4 v = row4[k >> 2];
-                    sum += v.x; sum += v.y; sum += v.z; sum += v.w;
+                    for (; k + 4 <= N; k += 4) {
+                        const float4 v = row4[k >> 2];
+                        sum += v.x; sum += v.y; sum += v.z; sum += v.w;
+                    }
+                    for (; k < N; ++k) sum += row[k];
+                    img[d - a.image_origin] = sum / (float)N;
                 }
-                for (; k < N; ++k) sum += row[k];
-                img[d - a.image_origin] = sum / (float)N;
             }
         }
     }
@@ -815,7 +822,14 @@ hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, in
         return hipGetLastError();
     };
     if constexpr (NC == 4 && (ALGO == ALGO_PAD || ALGO == ALGO_LERP)) {
-        if (plan.layout == 2) return go(copies::das_copies_kernel<ALGO>);
+        if (plan.layout == 2) {
+            switch (plan.dpw) {
+                case 4: return go(copies::das_copies_kernel<ALGO, 4>);
+                case 8: return go(copies::das_copies_kernel<ALGO, 8>);
+                case 16: return go(copies::das_copies_kernel<ALGO, 16>);
+                default: return hipErrorInvalidValue;
+            }
+        }
         if (plan.quad) {
             switch (plan.dpw) {
                 case 1: return go(das_mimo_kernel<ALGO, 4, 1, true>);
@@ -933,14 +947,18 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
         p.lead = round_up(L.tab.max_whole + 2, 4);       // lerp folds its extra sample into the delay (p + 1)
         p.row_stride = p.lead + 256;
         const size_t slot_bytes = (size_t)arrays * 4 * p.row_stride * sizeof(float);
-        int mc = (int)((80 * 1024) / slot_bytes);
+        // directions per wave: $BF_DPW or 16 (pad) / 8 (lerp) with one workgroup per CU; 4 = two 80 KiB workgroups per CU
+        int dpw = L.force_dpw > 0 ? L.force_dpw : (L.algo == ALGO_PAD ? 16 : 8);
+        if (dpw != 4 && dpw != 8 && dpw != 16) dpw = 4;
+        const size_t budget = dpw == 4 ? 80 * 1024 : 156 * 1024;
+        int mc = (int)(budget / slot_bytes);
         mc = mc >= 16 ? 16 : mc >= 8 ? 8 : mc;
         if (mc < 1) return fail(3);
         if (mc > L.n_mics) mc = L.n_mics;
         p.mic_chunk = mc; p.n_chunks = (L.n_mics + mc - 1) / mc;
-        p.waves = copies::kWaves; p.dpw = copies::kDpw; p.pbw = copies::kDpw; p.srow = copies::kParkStride;
+        p.waves = copies::kWaves; p.dpw = dpw; p.pbw = dpw >= 8 ? 8 : 4; p.srow = copies::kParkStride;
         p.scratch_off = 0;
-        const size_t park = (size_t)copies::kGroup * copies::kParkStride * sizeof(float);
+        const size_t park = (size_t)copies::kWaves * p.pbw * copies::kParkStride * sizeof(float);
         const size_t buf = slot_bytes * (size_t)mc;
         p.lds_bytes = buf > park ? buf : park;
     }
