@@ -178,6 +178,18 @@ __device__ __forceinline__ void accumulate(float (&acc)[NC], const float* lds, c
             const int p = wrow[ms];
             const float* __restrict__ h = trow + ms * T;
             const float* r = lds + ms * rs + (a.lead - p - 1 - T / 2) + lane;
+            if (T == 8) {   // the reference's N_TAPS: taps in scalar registers, tap loop unrolled
+                const float h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5], h6 = h[6], h7 = h[7];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float* x = r + c * kWave;
+                    float o = acc[c];
+                    o = __fmaf_rn(h0, x[0], o); o = __fmaf_rn(h1, x[1], o); o = __fmaf_rn(h2, x[2], o); o = __fmaf_rn(h3, x[3], o);
+                    o = __fmaf_rn(h4, x[4], o); o = __fmaf_rn(h5, x[5], o); o = __fmaf_rn(h6, x[6], o); o = __fmaf_rn(h7, x[7], o);
+                    acc[c] = (c * kWave <= p && !(lane + c * kWave > p)) ? acc[c] : o;   // samples with i < 0 receive nothing
+                }
+                continue;
+            }
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 float o = acc[c];
@@ -198,6 +210,18 @@ __device__ __forceinline__ void accumulate(float (&acc)[NC], const float* lds, c
         for (int ms = 0; ms < mc; ++ms) {
             const float* __restrict__ h = trow + ms * T;
             const float* r = lds + ms * rs + (a.lead - T / 2) + lane;
+            if (T == 8) {
+                const float h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5], h6 = h[6], h7 = h[7];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float* x = r + c * kWave;
+                    float o = acc[c];
+                    o = __fmaf_rn(h0, x[0], o); o = __fmaf_rn(h1, x[1], o); o = __fmaf_rn(h2, x[2], o); o = __fmaf_rn(h3, x[3], o);
+                    o = __fmaf_rn(h4, x[4], o); o = __fmaf_rn(h5, x[5], o); o = __fmaf_rn(h6, x[6], o); o = __fmaf_rn(h7, x[7], o);
+                    acc[c] = o;
+                }
+                continue;
+            }
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 float o = acc[c];
@@ -212,6 +236,16 @@ __device__ __forceinline__ void accumulate(float (&acc)[NC], const float* lds, c
         for (int ms = 0; ms < mc; ++ms) {
             const float* __restrict__ h = trow + ms * T;
             const float* r = lds + ms * rs + (a.lead - T / 2) + lane;
+            if (T == 8) {   // one AVX block: the eight fma lanes start from 0, i.e. they are plain products
+                const float h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5], h6 = h[6], h7 = h[7];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float* x = r + c * kWave;
+                    const float q0 = x[0] * h0 + x[4] * h4, q1 = x[1] * h1 + x[5] * h5, q2 = x[2] * h2 + x[6] * h6, q3 = x[3] * h3 + x[7] * h7;
+                    acc[c] += (q0 + q2) + (q1 + q3);
+                }
+                continue;
+            }
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f, l4 = 0.f, l5 = 0.f, l6 = 0.f, l7 = 0.f;
