@@ -39,7 +39,8 @@ struct DevBuf {
         if (n <= cap) return hipSuccess;
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
+        // 64 bytes of slack: the scalar-table kernels fetch 16 entries at a time and may run past the last row
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T) + 64);
         if (e == hipSuccess) cap = n;
         return e;
     }
@@ -54,7 +55,9 @@ struct TableSet {
     DevBuf<int32_t> whole;
     DevBuf<float> frac;
     DevBuf<float> taps;
-    void drop() { loaded = false; entries = 0; max_whole = 0; whole.release(); frac.release(); taps.release(); }
+    DevBuf<int32_t> digest;   // shifted-copies layout: LDS offsets per (direction, mic), see bf::launch_digest
+    long long digest_key = -1; // layout the digest was built for
+    void drop() { loaded = false; entries = 0; max_whole = 0; digest_key = -1; whole.release(); frac.release(); taps.release(); digest.release(); }
 };
 
 enum Slot { SLOT_PAD = 0, SLOT_LERP, SLOT_FIR, SLOT_HYBRID, SLOT_TRUNC, SLOT_COUNT };
@@ -268,8 +271,24 @@ bool plan_or_error(bf::DasLaunch& L, bf::DasPlan* plan)
     L.debug = debug;
     static const int dpw = [] { const char* e = getenv("BF_DPW"); return e ? atoi(e) : 0; }();
     L.force_dpw = dpw;
+    static const int stab = [] { const char* e = getenv("BF_STAB"); return e ? atoi(e) : 1; }();
+    L.scalar_table = stab;
     const char* why = "";
     if (bf::plan_das(L, S().n_cus, plan, &why) != 0) { set_error("unsupported shape: %s", why); return false; }
+    return true;
+}
+
+// Shifted-copies layout with scalar tables: make sure the table set carries a digest built for this plan.
+bool ensure_digest(TableSet& t, bf::DasLaunch& L, const bf::DasPlan& plan, hipStream_t stream)
+{
+    if (plan.layout != 2 || !plan.scalar_table) return true;
+    const long long key = ((long long)plan.mic_chunk << 40) ^ ((long long)plan.row_stride << 20) ^ ((long long)plan.lead << 4) ^ L.algo;
+    if (t.digest_key != key || !t.digest.p) {
+        if (!HIP_OK(t.digest.reserve((size_t)t.entries))) return false;
+        if (!HIP_OK(bf::launch_digest(t.whole.p, t.digest.p, t.entries, L.n_mics, plan, L.algo, stream))) return false;
+        t.digest_key = key;
+    }
+    L.tab.digest = t.digest.p;
     return true;
 }
 
@@ -294,6 +313,7 @@ void run_mimo_host(int algo, int slot, const float* signals, float* image, const
         ok = ok && HIP_OK(hipMemcpyAsync(s.d_frame.p, signals, rows * s.sz.n_samples * sizeof(float), hipMemcpyHostToDevice, s.stream));
         L.signals = s.d_frame.p; L.images = s.d_image.p; L.mics = s.d_mics.p;
         ok = ok && plan_or_error(L, &plan);
+        ok = ok && ensure_digest(s.tab[slot], L, plan, s.stream);
         ok = ok && HIP_OK(bf::launch_das(L, plan, s.stream));
         ok = ok && HIP_OK(hipMemcpyAsync(image, s.d_image.p, D * sizeof(float), hipMemcpyDeviceToHost, s.stream));
         ok = ok && HIP_OK(hipStreamSynchronize(s.stream));
@@ -758,6 +778,7 @@ int bf_das_device(int algo, const float* d_signals, int m_total, float* d_images
     L.dir_begin = dir_begin; L.dir_end = dir_end; L.image_stride = image_stride; L.image_origin = dir_begin;
     bf::DasPlan plan{};
     if (!plan_or_error(L, &plan)) return -1;
+    if (!ensure_digest(s.tab[slot], L, plan, reinterpret_cast<hipStream_t>(stream))) return -1;
     return HIP_OK(bf::launch_das(L, plan, reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
 }
 

@@ -22,6 +22,7 @@ struct DeviceTables {
     const float* frac = nullptr;     // [D][M]      h = 1 - frac              (lerp)
     const float* taps = nullptr;     // [D][M][T]   FIR taps                  (hybrid, fir)
     int max_whole = 0;               // max over the table, clamped to N (sizes the zero prefix in LDS)
+    const int32_t* digest = nullptr; // [D][M] LDS byte offsets for the shifted-copies layout (launch_digest), or null
 };
 
 // Geometry of one launch.  Directions [dir_begin, dir_end) of every frame in [0, frames).
@@ -41,6 +42,7 @@ struct DasLaunch {
     int frames;
     int force_layout;        // tests/bench ($BF_LAYOUT): -1 = planner's choice, else 0 / 1 / 2 for pad and lerp at N <= 256
     int debug;               // profiling switches ($BF_DEBUG), 0 in production
+    int scalar_table;        // shifted-copies layout: 1 = table entries through scalar loads of the digest ($BF_STAB, default 1)
     int force_dpw;           // tests/bench ($BF_DPW): directions per wave of the shifted-copies kernel (4, 8, 16); 0 = planner's choice
 };
 
@@ -56,6 +58,7 @@ struct DasPlan {
     int srow;        // scratch row stride in floats (64*nc + 4)
     int pbw;         // scratch rows (finished directions) per wave
     int quad;        // 1: lane owns 4 consecutive samples (ds_read_b128 + DPP), 0: lane-strided samples (ds_read_b32)
+    int scalar_table; // shifted-copies layout reads its table entries with scalar loads from DeviceTables::digest
     int layout;      // 0 strided, 1 quad + DPP, 2 shifted copies (pad / lerp, N <= 256)
     int dpw;         // directions a wave carries across mic chunks
     int tile_dirs;   // directions per workgroup
@@ -65,6 +68,9 @@ struct DasPlan {
 
 // Returns 0 and fills `plan`, or a negative value when the shape is unsupported (message in `why`).
 int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why);
+
+// Build DeviceTables::digest for the layout `plan` describes (shifted-copies layout only).
+hipError_t launch_digest(const int32_t* d_whole, int32_t* d_digest, long long entries, int n_mics, const DasPlan& plan, int algo, hipStream_t stream);
 
 // Enqueue on `stream`; no host synchronisation, no allocation (graph-capturable).
 hipError_t launch_das(const DasLaunch& L, const DasPlan& plan, hipStream_t stream);

@@ -621,6 +621,19 @@ __global__ void __launch_bounds__(64) das_miso_kernel(BF_TABLE_PARAMS, const flo
 //     in registers (global loads issued a chunk ahead) when the buffer is rewritten;
 //   * the chunk buffer (<= 80 KiB, two workgroups per CU) doubles as the scratch for the k-ordered power sum.
 // Mic order and operation order are unchanged, so the maps stay bit-identical to the CPU reference.
+// Digest of a `whole` table for the shifted-copies layout: entry (d, m) -> LDS byte offset of the aligned quad row that
+// direction d reads for staged mic m % mic_chunk (copy (p & 3), shifted back by p >> 2 quads; lerp reads one sample
+// earlier, p + 1).  Built once per (table, layout) so that the hot loop gets its addresses with scalar loads only.
+__global__ void __launch_bounds__(256) digest_kernel(const int32_t* __restrict__ whole, int32_t* __restrict__ digest, long long entries, int n_mics,
+                                                     int mic_chunk, int arrays, int row_stride, int lead, int bias)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < entries; i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i % n_mics) % mic_chunk;
+        const int pd = whole[i] + bias;
+        digest[i] = ((m * arrays * 4 + (pd & 3)) * row_stride + lead - (pd & ~3)) * 4;
+    }
+}
+
 namespace copies {
 
 constexpr int kWaves = 16;       // waves per workgroup
@@ -658,7 +671,7 @@ __device__ __forceinline__ void write_copies(float* row0, int rs, int lead, int 
 // DPW = directions a wave carries across the mic chunks (a multiple of 4).  A chunk is consumed between two
 // workgroup barriers, so the work per chunk per wave -- DPW x mic_chunk steps -- has to dwarf the barrier + restage
 // cost: DPW = 4 with two 80 KiB workgroups per CU, or DPW = 8 / 16 with one workgroup owning the whole LDS.
-template <int ALGO, int DPW>
+template <int ALGO, int DPW, bool STAB>
 __global__ void __launch_bounds__(1024, DPW == 4 ? 8 : 4) das_copies_kernel(BF_TABLE_PARAMS, KArgs a)
 {
     static_assert(ALGO == ALGO_PAD || ALGO == ALGO_LERP, "shifted-copies layout: pad and lerp");
@@ -730,7 +743,7 @@ __global__ void __launch_bounds__(1024, DPW == 4 ? 8 : 4) das_copies_kernel(BF_T
 
     float4 staged = fetch(0, min(mc, M));
     int vp_next[NQ]; float vh_next[NQ];
-    fetch_table(tile_begin, 0, min(mc, M), vp_next, vh_next);
+    if constexpr (!STAB) fetch_table(tile_begin, 0, min(mc, M), vp_next, vh_next);
 
     for (int g0 = tile_begin; g0 < tile_end; g0 += kGroup) {
         // Plain f32 VALU instructions occupy a SIMD for 4 cycles per wave64 on gfx950; the packed forms (v_pk_add_f32,
@@ -756,18 +769,72 @@ __global__ void __launch_bounds__(1024, DPW == 4 ? 8 : 4) das_copies_kernel(BF_T
             }
             __syncthreads();
             int ve[NQ]; float vh[NQ];
+            if constexpr (!STAB) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) { ve[q] = table_offsets(vp_next[q]); vh[q] = vh_next[q]; }
+                for (int q = 0; q < NQ; ++q) { ve[q] = table_offsets(vp_next[q]); vh[q] = vh_next[q]; }
+            }
             {   // request the next chunk (or the next group's first) while this one is consumed
                 int ng0 = g0, nch = ch + 1;
                 if (nch == a.n_chunks) { nch = 0; ng0 = g0 + kGroup; }
                 if (ng0 < tile_end) {
                     const int nm0 = nch * mc;
                     staged = fetch(nch, min(mc, M - nm0));
-                    fetch_table(ng0, nm0, min(mc, M - nm0), vp_next, vh_next);
+                    if constexpr (!STAB) fetch_table(ng0, nm0, min(mc, M - nm0), vp_next, vh_next);
                 }
             }
             const char* lbase = reinterpret_cast<const char*>(lds) + 16 * lane;
+            if constexpr (STAB) {
+                // Scalar-table path: the LDS offsets come pre-digested from memory (`taps` slot = int32 digest [D][M]) through
+                // s_load_dwordx16, the lerp weights straight from `frac`: no VALU slot is spent on table entries.  One
+                // direction at a time, its 16 staged mics in order, four reads in flight.
+                const int32_t* __restrict__ dig = reinterpret_cast<const int32_t*>(taps);
+                auto directions = [&](auto full_c) {
+                    constexpr bool FULL = decltype(full_c)::value;   // all 16 staged mics present: no per-mic conditionals
+#pragma unroll
+                    for (int j = 0; j < DPW; ++j) {
+                        const int d = g0 + wave * DPW + j;           // wave-uniform
+                        if (d >= tile_end) continue;
+                        const size_t idx = (size_t)d * M + m0;
+                        // 16 entries unconditionally (the tables carry 64 bytes of slack) so the loads merge into wide s_loads
+                        int e[16];
+                        float hh[16];
+#pragma unroll
+                        for (int m = 0; m < 16; ++m) {
+                            e[m] = dig[idx + m];
+                            hh[m] = 0.0f;
+                            if constexpr (ALGO == ALGO_LERP) hh[m] = frac[idx + m];
+                        }
+                        f32x2(&ac)[2] = acc[j];
+#pragma unroll
+                        for (int m4 = 0; m4 < 16; m4 += 4) {
+                            if (!FULL && m4 >= mcc) break;
+                            float4 S[4], Dq[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                // a partial chunk re-reads mic 0's row for the missing mics and drops the result
+                                const int eo = (FULL || m4 + u < mcc) ? e[m4 + u] : e[0];
+                                S[u] = *reinterpret_cast<const float4*>(lbase + eo);
+                                if constexpr (ALGO == ALGO_LERP) Dq[u] = *reinterpret_cast<const float4*>(lbase + eo + 16 * rs);
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                if (!FULL && m4 + u >= mcc) break;
+                                const f32x2 S01{S[u].x, S[u].y}, S23{S[u].z, S[u].w};
+                                if constexpr (ALGO == ALGO_PAD) {
+                                    // pad_and_sum.c:41-47   out[k] += s[k - p]
+                                    ac[0] += S01; ac[1] += S23;
+                                } else {
+                                    // lerp_and_sum.c:50-56  out[k] += s[i] + h * (s[i+1] - s[i]),  i = k - p - 1
+                                    const f32x2 h2{hh[m4 + u], hh[m4 + u]}, D01{Dq[u].x, Dq[u].y}, D23{Dq[u].z, Dq[u].w};
+                                    ac[0] += __builtin_elementwise_fma(h2, D01, S01);
+                                    ac[1] += __builtin_elementwise_fma(h2, D23, S23);
+                                }
+                            }
+                        }
+                    }
+                };
+                if (mcc == 16) directions(std::true_type{}); else directions(std::false_type{});
+            } else {
             // One batch = the 4 directions of table register q for staged mic m: all their LDS reads are issued before
             // any result is consumed (written this way because the compiler otherwise reuses one destination register
             // quad and waits for every read before issuing the next: one read in flight per wave).
@@ -805,6 +872,7 @@ __global__ void __launch_bounds__(1024, DPW == 4 ? 8 : 4) das_copies_kernel(BF_T
                 if constexpr (NQ > 2) { batch(std::integral_constant<int, 2>{}, m); batch(std::integral_constant<int, 3>{}, m); }
             };
             for (int m = 0; m < mcc; ++m) mic_steps(m);
+            }
         }
 
         // ---- k-ordered mean power of this wave's directions (rows alias the chunk buffer), kPark at a time
@@ -857,10 +925,26 @@ hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, in
     };
     if constexpr (NC == 4 && (ALGO == ALGO_PAD || ALGO == ALGO_LERP)) {
         if (plan.layout == 2) {
+            if (plan.scalar_table && L.tab.digest != nullptr) {
+                // the digest rides in the (unused) taps slot
+                auto go2 = [&](auto kernel) -> hipError_t {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
+                    if (e != hipSuccess) return e;
+                    hipLaunchKernelGGL(kernel, grid, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole, L.tab.frac,
+                                       reinterpret_cast<const float*>(L.tab.digest), a);
+                    return hipGetLastError();
+                };
+                switch (plan.dpw) {
+                    case 4: return go2(copies::das_copies_kernel<ALGO, 4, true>);
+                    case 8: return go2(copies::das_copies_kernel<ALGO, 8, true>);
+                    case 16: return go2(copies::das_copies_kernel<ALGO, 16, true>);
+                    default: return hipErrorInvalidValue;
+                }
+            }
             switch (plan.dpw) {
-                case 4: return go(copies::das_copies_kernel<ALGO, 4>);
-                case 8: return go(copies::das_copies_kernel<ALGO, 8>);
-                case 16: return go(copies::das_copies_kernel<ALGO, 16>);
+                case 4: return go(copies::das_copies_kernel<ALGO, 4, false>);
+                case 8: return go(copies::das_copies_kernel<ALGO, 8, false>);
+                case 16: return go(copies::das_copies_kernel<ALGO, 16, false>);
                 default: return hipErrorInvalidValue;
             }
         }
@@ -991,6 +1075,7 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
         if (mc > L.n_mics) mc = L.n_mics;
         p.mic_chunk = mc; p.n_chunks = (L.n_mics + mc - 1) / mc;
         p.waves = copies::kWaves; p.dpw = dpw; p.pbw = dpw >= 8 ? 8 : 4; p.srow = copies::kParkStride;
+        p.scalar_table = L.scalar_table ? 1 : 0;
         p.scratch_off = 0;
         const size_t park = (size_t)copies::kWaves * p.pbw * copies::kParkStride * sizeof(float);
         const size_t buf = slot_bytes * (size_t)mc;
@@ -1013,6 +1098,14 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
     *plan = p;
     if (why) *why = kWhy[0];
     return 0;
+}
+
+hipError_t launch_digest(const int32_t* d_whole, int32_t* d_digest, long long entries, int n_mics, const DasPlan& plan, int algo, hipStream_t stream)
+{
+    const int arrays = (algo == ALGO_LERP) ? 2 : 1, bias = (algo == ALGO_LERP) ? 1 : 0;
+    hipLaunchKernelGGL(digest_kernel, dim3(1024), dim3(256), 0, stream, d_whole, d_digest, entries, n_mics, plan.mic_chunk, arrays, plan.row_stride,
+                       plan.lead, bias);
+    return hipGetLastError();
 }
 
 hipError_t launch_das(const DasLaunch& L, const DasPlan& plan, hipStream_t stream)
