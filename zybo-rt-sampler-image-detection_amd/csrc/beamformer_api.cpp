@@ -269,10 +269,6 @@ bool plan_or_error(bf::DasLaunch& L, bf::DasPlan* plan)
     L.force_layout = layout;             // A/B switch for tests and profiling (see DasPlan::layout)
     static const int debug = [] { const char* e = getenv("BF_DEBUG"); return e ? atoi(e) : 0; }();
     L.debug = debug;
-    static const int dpw = [] { const char* e = getenv("BF_DPW"); return e ? atoi(e) : 0; }();
-    L.force_dpw = dpw;
-    static const int stab = [] { const char* e = getenv("BF_STAB"); return e ? atoi(e) : 1; }();
-    L.scalar_table = stab;
     const char* why = "";
     if (bf::plan_das(L, S().n_cus, plan, &why) != 0) { set_error("unsupported shape: %s", why); return false; }
     return true;
@@ -281,7 +277,7 @@ bool plan_or_error(bf::DasLaunch& L, bf::DasPlan* plan)
 // Shifted-copies layout with scalar tables: make sure the table set carries a digest built for this plan.
 bool ensure_digest(TableSet& t, bf::DasLaunch& L, const bf::DasPlan& plan, hipStream_t stream)
 {
-    if (plan.layout != 2 || !plan.scalar_table) return true;
+    if (plan.layout != 2) return true;
     const long long key = ((long long)plan.mic_chunk << 40) ^ ((long long)plan.row_stride << 20) ^ ((long long)plan.lead << 4) ^ L.algo;
     if (t.digest_key != key || !t.digest.p) {
         if (!HIP_OK(t.digest.reserve((size_t)t.entries))) return false;

@@ -41,9 +41,7 @@ struct DasLaunch {
     int image_stride, image_origin;
     int frames;
     int force_layout;        // tests/bench ($BF_LAYOUT): -1 = planner's choice, else 0 / 1 / 2 for pad and lerp at N <= 256
-    int debug;               // profiling switches ($BF_DEBUG), 0 in production
-    int scalar_table;        // shifted-copies layout: 1 = table entries through scalar loads of the digest ($BF_STAB, default 1)
-    int force_dpw;           // tests/bench ($BF_DPW): directions per wave of the shifted-copies kernel (4, 8, 16); 0 = planner's choice
+    int debug;               // profiling switches ($BF_DEBUG), 0 in production: bit 0 skip the power sum (strided kernel), bit 1 run-time row stride (copies kernel)
 };
 
 // Plan chosen on the host for a launch (exposed so tests can check LDS sizing without a GPU).
@@ -58,7 +56,6 @@ struct DasPlan {
     int srow;        // scratch row stride in floats (64*nc + 4)
     int pbw;         // scratch rows (finished directions) per wave
     int quad;        // 1: lane owns 4 consecutive samples (ds_read_b128 + DPP), 0: lane-strided samples (ds_read_b32)
-    int scalar_table; // shifted-copies layout reads its table entries with scalar loads from DeviceTables::digest
     int layout;      // 0 strided, 1 quad + DPP, 2 shifted copies (pad / lerp, N <= 256)
     int dpw;         // directions a wave carries across mic chunks
     int tile_dirs;   // directions per workgroup

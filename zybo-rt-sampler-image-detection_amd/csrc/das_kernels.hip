@@ -668,18 +668,27 @@ __device__ __forceinline__ void write_copies(float* row0, int rs, int lead, int 
     }
 }
 
-// DPW = directions a wave carries across the mic chunks (a multiple of 4).  A chunk is consumed between two
-// workgroup barriers, so the work per chunk per wave -- DPW x mic_chunk steps -- has to dwarf the barrier + restage
-// cost: DPW = 4 with two 80 KiB workgroups per CU, or DPW = 8 / 16 with one workgroup owning the whole LDS.
-template <int ALGO, int DPW, bool STAB>
-__global__ void __launch_bounds__(1024, DPW == 4 ? 8 : 4) das_copies_kernel(BF_TABLE_PARAMS, KArgs a)
+constexpr int kDpw = 8;          // directions a wave carries across the mic chunks
+constexpr int kGroup = kDpw * kWaves;   // directions per workgroup pass
+constexpr int kFixedRs = 304;    // compile-time row stride (lead 48) used when the largest delay allows it
+constexpr int kFixedLead = 48;
+
+// One workgroup (16 waves, one per CU: it owns the LDS) walks a tile of directions in groups of 128; for each group
+// the frame's mics pass through LDS in chunks of <= 16 (each staged as 4 shifted copies, lerp also 4 copies of the
+// first difference), every wave accumulating its 8 directions in registers across the chunks.  A chunk is consumed
+// between two workgroup barriers, so the work per chunk per wave -- 8 x mic_chunk steps -- dwarfs the barrier + restage
+// cost, and the next chunk's global loads are in flight meanwhile.
+//
+// Table entries never touch the VALU: the `taps` slot carries the int32 digest [D][M] (digest_kernel: LDS byte offset
+// per (direction, mic)), fetched with s_load_dwordx16 like the lerp weights in `frac`.  Per (direction, mic) the wave
+// issues  pad: 1 v_add (address) + 1 ds_read_b128 + 2 v_pk_add_f32;  lerp: 1-2 v_add + 2 ds_read_b128 + 2 v_pk_fma_f32 +
+// 2 v_pk_add_f32.  RS > 0 fixes the row stride at compile time so that the D read is the s read plus an immediate offset.
+template <int ALGO, int RS>
+__global__ void __launch_bounds__(1024, 4) das_copies_kernel(BF_TABLE_PARAMS, KArgs a)
 {
     static_assert(ALGO == ALGO_PAD || ALGO == ALGO_LERP, "shifted-copies layout: pad and lerp");
-    static_assert(DPW % 4 == 0 && DPW <= 16, "directions per wave");
     constexpr int A = (ALGO == ALGO_LERP) ? 2 : 1;   // arrays per mic: s (and D)
-    constexpr int NQ = DPW / 4;                      // table registers: each holds 4 directions x 16 mics
-    constexpr int kPark = DPW >= 8 ? 8 : 4;          // rows parked (and chained) per wave at a time
-    constexpr int kGroup = DPW * kWaves;
+    constexpr int DPW = kDpw;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -690,9 +699,11 @@ __global__ void __launch_bounds__(1024, DPW == 4 ? 8 : 4) das_copies_kernel(BF_T
     if (tile_begin >= a.dir_end) return;
     const int tile_end = min(tile_begin + a.tile_dirs, a.dir_end);
 
-    const int rs = a.row_stride, lead = a.lead, mc = a.mic_chunk, M = a.n_mics, N = a.n_samples;
+    const int rs = RS > 0 ? RS : a.row_stride, lead = RS > 0 ? kFixedLead : a.lead;
+    const int mc = a.mic_chunk, M = a.n_mics, N = a.n_samples;
     const float* __restrict__ frame_sig = signals + (size_t)frame * a.m_total * N;
     float* __restrict__ img = images + (size_t)frame * a.image_stride;
+    const int32_t* __restrict__ dig = reinterpret_cast<const int32_t*>(taps);
     const int slot_floats = A * 4 * rs;   // floats per staged mic
 
     // Row of `signals` this wave stages in chunk c: mics[c*mc + wave].  Loaded once (lane c holds chunk c's row) so
@@ -718,37 +729,13 @@ __global__ void __launch_bounds__(1024, DPW == 4 ? 8 : 4) das_copies_kernel(BF_T
         }
         return v;
     };
-    // raw table entries of one chunk: register q, lane 16 j + m  <->  direction 4 q + j of this wave, staged mic m.
-    // Nothing here touches the loaded values, so the loads stay in flight until table_offsets() a chunk later.
-    auto fetch_table = [&](int g0, int m0, int mcc, int (&vp)[NQ], float (&vh)[NQ]) {
-        const int j = lane >> 4, m = lane & 15;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int d = g0 + wave * DPW + 4 * q + j;
-            vp[q] = 0; vh[q] = 0.0f;
-            if (m < mcc && d < tile_end) {
-                const size_t idx = (size_t)d * M + m0 + m;
-                vp[q] = whole[idx];
-                if constexpr (ALGO == ALGO_LERP) vh[q] = frac[idx];
-            }
-        }
-    };
-    // delay -> LDS byte offset of the aligned quad row: copy (p & 3) of staged mic m, shifted back by p >> 2 quads
-    auto table_offsets = [&](int vp) -> int {
-        const int m = lane & 15;
-        int pd = vp;
-        if constexpr (ALGO == ALGO_LERP) pd += 1;   // lerp reads s[k - p - 1]
-        return ((m * A * 4 + (pd & 3)) * rs + lead - (pd & ~3)) * 4;
-    };
 
     float4 staged = fetch(0, min(mc, M));
-    int vp_next[NQ]; float vh_next[NQ];
-    if constexpr (!STAB) fetch_table(tile_begin, 0, min(mc, M), vp_next, vh_next);
+    const char* lbase = reinterpret_cast<const char*>(lds) + 16 * lane;
 
     for (int g0 = tile_begin; g0 < tile_end; g0 += kGroup) {
-        // Plain f32 VALU instructions occupy a SIMD for 4 cycles per wave64 on gfx950; the packed forms (v_pk_add_f32,
-        // v_pk_fma_f32) do two lanes' worth of IEEE-identical work in the same slot, so the accumulators are kept as
-        // two float2 register pairs matching the (x,y)/(z,w) halves of a quad read.
+        // v_pk_add_f32 / v_pk_fma_f32 keep the instruction count down (IEEE-identical to the scalar forms); the
+        // accumulators are two float2 register pairs matching the (x,y)/(z,w) halves of a quad read.
         f32x2 acc[DPW][2];
 #pragma unroll
         for (int j = 0; j < DPW; ++j) { acc[j][0] = f32x2{0.0f, 0.0f}; acc[j][1] = f32x2{0.0f, 0.0f}; }
@@ -768,142 +755,92 @@ __global__ void __launch_bounds__(1024, DPW == 4 ? 8 : 4) das_copies_kernel(BF_T
                 }
             }
             __syncthreads();
-            int ve[NQ]; float vh[NQ];
-            if constexpr (!STAB) {
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) { ve[q] = table_offsets(vp_next[q]); vh[q] = vh_next[q]; }
-            }
             {   // request the next chunk (or the next group's first) while this one is consumed
                 int ng0 = g0, nch = ch + 1;
                 if (nch == a.n_chunks) { nch = 0; ng0 = g0 + kGroup; }
-                if (ng0 < tile_end) {
-                    const int nm0 = nch * mc;
-                    staged = fetch(nch, min(mc, M - nm0));
-                    if constexpr (!STAB) fetch_table(ng0, nm0, min(mc, M - nm0), vp_next, vh_next);
-                }
+                if (ng0 < tile_end) staged = fetch(nch, min(mc, M - nch * mc));
             }
-            const char* lbase = reinterpret_cast<const char*>(lds) + 16 * lane;
-            if constexpr (STAB) {
-                // Scalar-table path: the LDS offsets come pre-digested from memory (`taps` slot = int32 digest [D][M]) through
-                // s_load_dwordx16, the lerp weights straight from `frac`: no VALU slot is spent on table entries.  One
-                // direction at a time, its 16 staged mics in order, four reads in flight.
-                const int32_t* __restrict__ dig = reinterpret_cast<const int32_t*>(taps);
-                auto directions = [&](auto full_c) {
-                    constexpr bool FULL = decltype(full_c)::value;   // all 16 staged mics present: no per-mic conditionals
+            // One direction at a time, its staged mics in order, four mics' reads in flight.
+            auto directions = [&](auto full_c) {
+                constexpr bool FULL = decltype(full_c)::value;   // all 16 staged mics present: no per-mic conditionals
 #pragma unroll
-                    for (int j = 0; j < DPW; ++j) {
-                        const int d = g0 + wave * DPW + j;           // wave-uniform
-                        if (d >= tile_end) continue;
-                        const size_t idx = (size_t)d * M + m0;
-                        // 16 entries unconditionally (the tables carry 64 bytes of slack) so the loads merge into wide s_loads
-                        int e[16];
-                        float hh[16];
+                for (int j = 0; j < DPW; ++j) {
+                    const int d = g0 + wave * DPW + j;           // wave-uniform
+                    if (d >= tile_end) continue;
+                    const size_t idx = (size_t)d * M + m0;
+                    // 16 entries unconditionally (the tables carry 64 bytes of slack) so the loads merge into wide s_loads
+                    int e[16];
+                    float hh[16];
 #pragma unroll
-                        for (int m = 0; m < 16; ++m) {
-                            e[m] = dig[idx + m];
-                            hh[m] = 0.0f;
-                            if constexpr (ALGO == ALGO_LERP) hh[m] = frac[idx + m];
+                    for (int m = 0; m < 16; ++m) {
+                        e[m] = dig[idx + m];
+                        hh[m] = 0.0f;
+                        if constexpr (ALGO == ALGO_LERP) hh[m] = frac[idx + m];
+                    }
+                    f32x2(&ac)[2] = acc[j];
+#pragma unroll
+                    for (int m4 = 0; m4 < 16; m4 += 4) {
+                        if (!FULL && m4 >= mcc) break;
+                        float4 S[4], Dq[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            // a partial chunk re-reads mic 0's row for the missing mics and drops the result
+                            const int eo = (FULL || m4 + u < mcc) ? e[m4 + u] : e[0];
+                            const char* sp = lbase + eo;
+                            S[u] = *reinterpret_cast<const float4*>(sp);
+                            if constexpr (ALGO == ALGO_LERP) Dq[u] = *reinterpret_cast<const float4*>(sp + 16 * rs);   // D copies: 4 rows on
                         }
-                        f32x2(&ac)[2] = acc[j];
 #pragma unroll
-                        for (int m4 = 0; m4 < 16; m4 += 4) {
-                            if (!FULL && m4 >= mcc) break;
-                            float4 S[4], Dq[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                // a partial chunk re-reads mic 0's row for the missing mics and drops the result
-                                const int eo = (FULL || m4 + u < mcc) ? e[m4 + u] : e[0];
-                                S[u] = *reinterpret_cast<const float4*>(lbase + eo);
-                                if constexpr (ALGO == ALGO_LERP) Dq[u] = *reinterpret_cast<const float4*>(lbase + eo + 16 * rs);
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                if (!FULL && m4 + u >= mcc) break;
-                                const f32x2 S01{S[u].x, S[u].y}, S23{S[u].z, S[u].w};
-                                if constexpr (ALGO == ALGO_PAD) {
-                                    // pad_and_sum.c:41-47   out[k] += s[k - p]
-                                    ac[0] += S01; ac[1] += S23;
-                                } else {
-                                    // lerp_and_sum.c:50-56  out[k] += s[i] + h * (s[i+1] - s[i]),  i = k - p - 1
-                                    const f32x2 h2{hh[m4 + u], hh[m4 + u]}, D01{Dq[u].x, Dq[u].y}, D23{Dq[u].z, Dq[u].w};
-                                    ac[0] += __builtin_elementwise_fma(h2, D01, S01);
-                                    ac[1] += __builtin_elementwise_fma(h2, D23, S23);
-                                }
+                        for (int u = 0; u < 4; ++u) {
+                            if (!FULL && m4 + u >= mcc) break;
+                            const f32x2 S01{S[u].x, S[u].y}, S23{S[u].z, S[u].w};
+                            if constexpr (ALGO == ALGO_PAD) {
+                                // pad_and_sum.c:41-47   out[k] += s[k - p]
+                                ac[0] += S01; ac[1] += S23;
+                            } else {
+                                // lerp_and_sum.c:50-56  out[k] += s[i] + h * (s[i+1] - s[i]),  i = k - p - 1
+                                const f32x2 h2{hh[m4 + u], hh[m4 + u]}, D01{Dq[u].x, Dq[u].y}, D23{Dq[u].z, Dq[u].w};
+                                ac[0] += __builtin_elementwise_fma(h2, D01, S01);
+                                ac[1] += __builtin_elementwise_fma(h2, D23, S23);
                             }
                         }
                     }
-                };
-                if (mcc == 16) directions(std::true_type{}); else directions(std::false_type{});
-            } else {
-            // One batch = the 4 directions of table register q for staged mic m: all their LDS reads are issued before
-            // any result is consumed (written this way because the compiler otherwise reuses one destination register
-            // quad and waits for every read before issuing the next: one read in flight per wave).
-            auto batch = [&](auto qc, int m) {
-                constexpr int q = decltype(qc)::value;
-                float4 S[4], Dq[4];
-                float h[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int e = __builtin_amdgcn_readlane(ve[q], 16 * j + m);
-                    S[j] = *reinterpret_cast<const float4*>(lbase + e);
-                    if constexpr (ALGO == ALGO_LERP) {
-                        Dq[j] = *reinterpret_cast<const float4*>(lbase + e + 16 * rs);   // D copies sit 4 rows after the s copies
-                        h[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vh[q]), 16 * j + m));
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x2(&ac)[2] = acc[4 * q + j];
-                    const f32x2 S01{S[j].x, S[j].y}, S23{S[j].z, S[j].w};
-                    if constexpr (ALGO == ALGO_PAD) {
-                        // pad_and_sum.c:41-47   out[k] += s[k - p]
-                        ac[0] += S01; ac[1] += S23;
-                    } else {
-                        // lerp_and_sum.c:50-56  out[k] += s[i] + h * (s[i+1] - s[i]),  i = k - p - 1
-                        const f32x2 h2{h[j], h[j]}, D01{Dq[j].x, Dq[j].y}, D23{Dq[j].z, Dq[j].w};
-                        ac[0] += __builtin_elementwise_fma(h2, D01, S01);
-                        ac[1] += __builtin_elementwise_fma(h2, D23, S23);
-                    }
                 }
             };
-            auto mic_steps = [&](int m) {
-                batch(std::integral_constant<int, 0>{}, m);
-                if constexpr (NQ > 1) batch(std::integral_constant<int, 1>{}, m);
-                if constexpr (NQ > 2) { batch(std::integral_constant<int, 2>{}, m); batch(std::integral_constant<int, 3>{}, m); }
-            };
-            for (int m = 0; m < mcc; ++m) mic_steps(m);
-            }
+            if (mcc == 16) directions(std::true_type{}); else directions(std::false_type{});
         }
 
-        // ---- k-ordered mean power of this wave's directions (rows alias the chunk buffer), kPark at a time
+        // ---- k-ordered mean power (pad_and_sum.c:120-128): every wave parks the squared means of its 8 directions
+        // (row = direction within the group; the rows alias the chunk buffer), then two waves run the sequential
+        // sums with one direction per lane: 64 chains per instruction instead of 8, and coalesced image stores.
         __syncthreads();
-        float* rows = lds + wave * kPark * kParkStride;
 #pragma unroll
-        for (int r0 = 0; r0 < DPW; r0 += kPark) {
+        for (int j = 0; j < DPW; ++j) {
+            const f32x2 a0 = acc[j][0], a1 = acc[j][1];
+            const float o0 = a.n_is_pow2 ? a0.x * a.inv_n : a0.x / (float)M;
+            const float o1 = a.n_is_pow2 ? a0.y * a.inv_n : a0.y / (float)M;
+            const float o2 = a.n_is_pow2 ? a1.x * a.inv_n : a1.x / (float)M;
+            const float o3 = a.n_is_pow2 ? a1.y * a.inv_n : a1.y / (float)M;
+            reinterpret_cast<float4*>(lds + (wave * DPW + j) * kParkStride)[lane] = make_float4(o0 * o0, o1 * o1, o2 * o2, o3 * o3);
+        }
+        __syncthreads();
+        if (wave < kGroup / kWave) {
+            const int g = wave * kWave + lane;
+            const int d = g0 + g;
+            if (d < tile_end) {
+                const float* row = lds + g * kParkStride;
+                const float4* row4 = reinterpret_cast<const float4*>(row);
+                float sum = 0.0f;
+                int k = 0;
+                for (; k + 32 <= N; k += 32) {
+                    float4 v[8];
 #pragma unroll
-            for (int j = 0; j < kPark; ++j) {
-                const f32x2 a0 = acc[r0 + j][0], a1 = acc[r0 + j][1];
-                const float o0 = a.n_is_pow2 ? a0.x * a.inv_n : a0.x / (float)M;
-                const float o1 = a.n_is_pow2 ? a0.y * a.inv_n : a0.y / (float)M;
-                const float o2 = a.n_is_pow2 ? a1.x * a.inv_n : a1.x / (float)M;
-                const float o3 = a.n_is_pow2 ? a1.y * a.inv_n : a1.y / (float)M;
-                reinterpret_cast<float4*>(rows + j * kParkStride)[lane] = make_float4(o0 * o0, o1 * o1, o2 * o2, o3 * o3);
-            }
-            if (lane < kPark) {
-                const int d = g0 + wave * DPW + r0 + lane;
-                if (d < tile_end) {
-                    const float* row = rows + lane * kParkStride;
-                    const float4* row4 = reinterpret_cast<const float4*>(row);
-                    float sum = 0.0f;
-                    int k = 0;
-#pragma unroll 4
-                    for (; k + 4 <= N; k += 4) {
-                        const float4 v = row4[k >> 2];
-                        sum += v.x; sum += v.y; sum += v.z; sum += v.w;
-                    }
-                    for (; k < N; ++k) sum += row[k];
-                    img[d - a.image_origin] = sum / (float)N;
+                    for (int u = 0; u < 8; ++u) v[u] = row4[(k >> 2) + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { sum += v[u].x; sum += v[u].y; sum += v[u].z; sum += v[u].w; }
                 }
+                for (; k < N; ++k) sum += row[k];
+                img[d - a.image_origin] = sum / (float)N;
             }
         }
     }
@@ -925,28 +862,17 @@ hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, in
     };
     if constexpr (NC == 4 && (ALGO == ALGO_PAD || ALGO == ALGO_LERP)) {
         if (plan.layout == 2) {
-            if (plan.scalar_table && L.tab.digest != nullptr) {
-                // the digest rides in the (unused) taps slot
-                auto go2 = [&](auto kernel) -> hipError_t {
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
-                    if (e != hipSuccess) return e;
-                    hipLaunchKernelGGL(kernel, grid, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole, L.tab.frac,
-                                       reinterpret_cast<const float*>(L.tab.digest), a);
-                    return hipGetLastError();
-                };
-                switch (plan.dpw) {
-                    case 4: return go2(copies::das_copies_kernel<ALGO, 4, true>);
-                    case 8: return go2(copies::das_copies_kernel<ALGO, 8, true>);
-                    case 16: return go2(copies::das_copies_kernel<ALGO, 16, true>);
-                    default: return hipErrorInvalidValue;
-                }
-            }
-            switch (plan.dpw) {
-                case 4: return go(copies::das_copies_kernel<ALGO, 4, false>);
-                case 8: return go(copies::das_copies_kernel<ALGO, 8, false>);
-                case 16: return go(copies::das_copies_kernel<ALGO, 16, false>);
-                default: return hipErrorInvalidValue;
-            }
+            if (L.tab.digest == nullptr) return hipErrorInvalidValue;   // launch_digest first
+            // the digest rides in the (unused) taps slot
+            auto go2 = [&](auto kernel) -> hipError_t {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(kernel, grid, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole, L.tab.frac,
+                                   reinterpret_cast<const float*>(L.tab.digest), a);
+                return hipGetLastError();
+            };
+            return plan.row_stride == copies::kFixedRs && plan.lead == copies::kFixedLead ? go2(copies::das_copies_kernel<ALGO, copies::kFixedRs>)
+                                                                                          : go2(copies::das_copies_kernel<ALGO, 0>);
         }
         if (plan.quad) {
             switch (plan.dpw) {
@@ -1063,21 +989,17 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
     if (p.layout == 2) {
         const int arrays = (L.algo == ALGO_LERP) ? 2 : 1;
         p.lead = round_up(L.tab.max_whole + 2, 4);       // lerp folds its extra sample into the delay (p + 1)
+        if (p.lead <= copies::kFixedLead && !(L.debug & 2)) p.lead = copies::kFixedLead;   // compile-time row stride
         p.row_stride = p.lead + 256;
         const size_t slot_bytes = (size_t)arrays * 4 * p.row_stride * sizeof(float);
-        // directions per wave: $BF_DPW or 16 (pad) / 8 (lerp) with one workgroup per CU; 4 = two 80 KiB workgroups per CU
-        int dpw = L.force_dpw > 0 ? L.force_dpw : (L.algo == ALGO_PAD ? 16 : 8);
-        if (dpw != 4 && dpw != 8 && dpw != 16) dpw = 4;
-        const size_t budget = dpw == 4 ? 80 * 1024 : 156 * 1024;
-        int mc = (int)(budget / slot_bytes);
+        int mc = (int)((size_t)156 * 1024 / slot_bytes);
         mc = mc >= 16 ? 16 : mc >= 8 ? 8 : mc;
         if (mc < 1) return fail(3);
         if (mc > L.n_mics) mc = L.n_mics;
         p.mic_chunk = mc; p.n_chunks = (L.n_mics + mc - 1) / mc;
-        p.waves = copies::kWaves; p.dpw = dpw; p.pbw = dpw >= 8 ? 8 : 4; p.srow = copies::kParkStride;
-        p.scalar_table = L.scalar_table ? 1 : 0;
+        p.waves = copies::kWaves; p.dpw = copies::kDpw; p.pbw = copies::kDpw; p.srow = copies::kParkStride;
         p.scratch_off = 0;
-        const size_t park = (size_t)copies::kWaves * p.pbw * copies::kParkStride * sizeof(float);
+        const size_t park = (size_t)copies::kGroup * copies::kParkStride * sizeof(float);
         const size_t buf = slot_bytes * (size_t)mc;
         p.lds_bytes = buf > park ? buf : park;
     }
