@@ -152,11 +152,19 @@ def main():
     import torch
     import torch.distributed as dist
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # $BF_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: ranks share the cards and the
+    # heat-map gather is staged through the host.  The measured configuration is always nccl (= RCCL over xGMI).
+    backend = os.environ.get("BF_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from interface import config
     from lib import _native as nat
@@ -195,20 +203,43 @@ def main():
     d_sig = torch.from_numpy(np.tile(host, (reps, 1, 1))[:frames_global]).to(dev)
     lo, hi = multi_gpu.shard_range(D, world, rank)
     shard_cap = multi_gpu.shard_capacity(D, world)
-    d_part = torch.zeros((frames_global, shard_cap), dtype=torch.float32, device=dev)
-    d_full = torch.zeros((world * frames_global, shard_cap), dtype=torch.float32, device=dev) if world > 1 else None
+    # two heat-map buffers: the all-gather of step k (RCCL's own stream) overlaps the beamforming kernel of step k + 1
+    nbuf = 2 if world > 1 else 1
+    d_part = [torch.zeros((frames_global, shard_cap), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+    d_full = [torch.zeros((world * frames_global, shard_cap), dtype=torch.float32, device=dev) for _ in range(nbuf)] if world > 1 else None
+    pending = [None] * nbuf
     stream = torch.cuda.current_stream()
 
-    def step():
-        rc = nat.lib.bf_das_device(algo_id, d_sig.data_ptr(), M, d_part.data_ptr(), shard_cap, frames_global, nat.iptr(mics), M,
+    def gather(k):
+        b = k % nbuf
+        if backend == "nccl":
+            pending[b] = dist.all_gather_into_tensor(d_full[b], d_part[b], async_op=True)
+        else:
+            out = torch.empty(d_full[b].shape, dtype=torch.float32)
+            dist.all_gather_into_tensor(out, d_part[b].cpu())
+            d_full[b].copy_(out)
+
+    def beamform(k):
+        b = k % nbuf
+        if pending[b] is not None:
+            pending[b].wait()          # the gather that last read this buffer (stream-level wait, the host runs on)
+            pending[b] = None
+        rc = nat.lib.bf_das_device(algo_id, d_sig.data_ptr(), M, d_part[b].data_ptr(), shard_cap, frames_global, nat.iptr(mics), M,
                                    lo, hi, stream.cuda_stream)
         if rc != 0:
             nat.check()
-        if world > 1:
-            dist.all_gather_into_tensor(d_full, d_part)
 
-    for _ in range(args.warmup):
-        step()
+    def drain():
+        for b in range(nbuf):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+
+    for k in range(args.warmup):
+        beamform(k)
+        if world > 1:
+            gather(k)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -219,25 +250,28 @@ def main():
     for k in range(args.steps):
         # HIP events on the launch stream bracket the beamforming kernel only (not the collective)
         ev[k][0].record(stream)
-        rc = nat.lib.bf_das_device(algo_id, d_sig.data_ptr(), M, d_part.data_ptr(), shard_cap, frames_global, nat.iptr(mics), M,
-                                   lo, hi, stream.cuda_stream)
+        beamform(k)
         ev[k][1].record(stream)
-        if rc != 0:
-            nat.check()
         if world > 1:
-            dist.all_gather_into_tensor(d_full, d_part)
+            gather(k)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    assert torch.isfinite(d_part[:, : hi - lo]).all(), "non-finite beam power"
+    assert torch.isfinite(d_part[0][:, : hi - lo]).all(), "non-finite beam power"
+    if world > 1:
+        # every rank now holds every shard: check the assembled map against this rank's own shard of the last step
+        last = (args.steps - 1) % nbuf
+        mine = d_full[last][rank * frames_global:(rank + 1) * frames_global, : hi - lo]
+        assert torch.equal(mine, d_part[last][:, : hi - lo]), "all-gather returned a different shard"
 
     if rank == 0:
         fps = frames_global * args.steps / elapsed
