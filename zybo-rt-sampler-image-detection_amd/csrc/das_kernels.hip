@@ -637,7 +637,6 @@ __global__ void __launch_bounds__(256) digest_kernel(const int32_t* __restrict__
 namespace copies {
 
 constexpr int kWaves = 16;       // waves per workgroup
-constexpr int kParkStride = 260; // floats per parked row (256 squares, 16-byte aligned rows)
 
 __device__ __forceinline__ float dpp_prev(float x)   // lane-1's value, 0 in lane 0
 {
@@ -647,48 +646,58 @@ __device__ __forceinline__ float dpp_next(float x)   // lane+1's value, 0 in lan
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130, 0xf, 0xf, true));
 }
+__device__ __forceinline__ float lane_value(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
 
-// Write the four shifted copies of one quad-per-lane row: copy c holds s shifted right by c samples, i.e. its
-// aligned quad i is (s[4i-c], ..., s[4i-c+3]); the leading values come from the previous lane.
-__device__ __forceinline__ void write_copies(float* row0, int rs, int lead, int lane, float4 v)
+// Geometry of the shifted-copies layout for a block of NSEG x 256 samples (N <= 256: 1, <= 512: 2, <= 1024: 4).
+//   * a wave owns DW directions x NSEG segments of 256 samples (one aligned quad per lane per segment);
+//   * compile-time row stride (RS > 0) when the largest delay fits kLead: the D / segment reads become immediate offsets.
+template <int NSEG>
+struct Geo {
+    static constexpr int kDw = NSEG == 1 ? 8 : NSEG == 2 ? 8 : 4;   // directions per wave
+    static constexpr int kGroup = kDw * kWaves;                      // directions per workgroup pass
+    static constexpr int kBatch = 4 / NSEG;                          // mics whose reads are in flight together
+    static constexpr int kLead = NSEG == 1 ? 48 : 64;                // zero prefix of the fixed-stride variant
+    static constexpr int kRs = NSEG * 256 + kLead;                   // its row stride
+    static constexpr int kPark = NSEG * 256 + 4;                     // floats per parked row of squares
+};
+
+// What one thread holds of a staged (mic, segment) pair between its global load and its LDS write.
+struct Staged {
+    float4 v;     // samples 4q .. 4q+3, q = 64 seg + lane
+    float edge;   // NSEG > 1: lanes 0..2 hold s[4q-3 .. 4q-1] of the segment's first quad, lane 63 holds s[4q+4] of its last
+};
+
+// Write the four shifted copies of a segment: copy c holds the row shifted right by c samples, i.e. its aligned
+// quad i is (x[4i-c], ..., x[4i-c+3]); (py, pz, pw) are x[4q-3 .. 4q-1] (previous lane, or the segment edge).
+__device__ __forceinline__ void write_copies(float* row0, int rs, int col, int lane, float4 v, float py, float pz, float pw)
 {
-    const float py = dpp_prev(v.y), pz = dpp_prev(v.z), pw = dpp_prev(v.w);
-    float4* q0 = reinterpret_cast<float4*>(row0 + 0 * rs + lead) + lane;
-    float4* q1 = reinterpret_cast<float4*>(row0 + 1 * rs + lead) + lane;
-    float4* q2 = reinterpret_cast<float4*>(row0 + 2 * rs + lead) + lane;
-    float4* q3 = reinterpret_cast<float4*>(row0 + 3 * rs + lead) + lane;
+    float4* q0 = reinterpret_cast<float4*>(row0 + 0 * rs + col) + lane;
+    float4* q1 = reinterpret_cast<float4*>(row0 + 1 * rs + col) + lane;
+    float4* q2 = reinterpret_cast<float4*>(row0 + 2 * rs + col) + lane;
+    float4* q3 = reinterpret_cast<float4*>(row0 + 3 * rs + col) + lane;
     *q0 = v;
     *q1 = make_float4(pw, v.x, v.y, v.z);
     *q2 = make_float4(pz, pw, v.x, v.y);
     *q3 = make_float4(py, pz, pw, v.x);
-    if (lane < (lead >> 2)) {   // the zero prefix (also wiped by the parked rows of the previous group)
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) reinterpret_cast<float4*>(row0 + c * rs)[lane] = z;
-    }
 }
 
-constexpr int kDpw = 8;          // directions a wave carries across the mic chunks
-constexpr int kGroup = kDpw * kWaves;   // directions per workgroup pass
-constexpr int kFixedRs = 304;    // compile-time row stride (lead 48) used when the largest delay allows it
-constexpr int kFixedLead = 48;
-
-// One workgroup (16 waves, one per CU: it owns the LDS) walks a tile of directions in groups of 128; for each group
-// the frame's mics pass through LDS in chunks of <= 16 (each staged as 4 shifted copies, lerp also 4 copies of the
-// first difference), every wave accumulating its 8 directions in registers across the chunks.  A chunk is consumed
-// between two workgroup barriers, so the work per chunk per wave -- 8 x mic_chunk steps -- dwarfs the barrier + restage
-// cost, and the next chunk's global loads are in flight meanwhile.
+// One workgroup (16 waves, one per CU: it owns the LDS) walks a tile of directions in groups of kGroup; for each group
+// the frame's mics pass through LDS in chunks (each mic staged as 4 shifted copies, lerp also 4 copies of the first
+// difference), every wave accumulating its directions in registers across the chunks.  A chunk is consumed between
+// two workgroup barriers and the next chunk's global loads are in flight meanwhile.
 //
 // Table entries never touch the VALU: the `taps` slot carries the int32 digest [D][M] (digest_kernel: LDS byte offset
-// per (direction, mic)), fetched with s_load_dwordx16 like the lerp weights in `frac`.  Per (direction, mic) the wave
-// issues  pad: 1 v_add (address) + 1 ds_read_b128 + 2 v_pk_add_f32;  lerp: 1-2 v_add + 2 ds_read_b128 + 2 v_pk_fma_f32 +
-// 2 v_pk_add_f32.  RS > 0 fixes the row stride at compile time so that the D read is the s read plus an immediate offset.
-template <int ALGO, int RS>
+// per (direction, mic)), fetched with s_load_dwordx16 like the lerp weights in `frac`.  Per (direction, mic, segment)
+// the wave issues  pad: 1 ds_read_b128 + 2 v_pk_add_f32;  lerp: 2 ds_read_b128 + 2 v_pk_fma_f32 + 2 v_pk_add_f32, plus
+// one v_add per (direction, mic) for the address (two for lerp with a run-time row stride).
+template <int ALGO, int NSEG, int RS>
 __global__ void __launch_bounds__(1024, 4) das_copies_kernel(BF_TABLE_PARAMS, KArgs a)
 {
     static_assert(ALGO == ALGO_PAD || ALGO == ALGO_LERP, "shifted-copies layout: pad and lerp");
+    static_assert(RS == 0 || RS == Geo<NSEG>::kRs, "fixed row stride");
     constexpr int A = (ALGO == ALGO_LERP) ? 2 : 1;   // arrays per mic: s (and D)
-    constexpr int DPW = kDpw;
+    constexpr int DW = Geo<NSEG>::kDw, U = Geo<NSEG>::kBatch, kGroup = Geo<NSEG>::kGroup, kPark = Geo<NSEG>::kPark;
+    constexpr int SP = (NSEG > 1 && ALGO == ALGO_PAD) ? 2 : 1;   // (mic, segment) pairs a wave stages per chunk
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -699,73 +708,117 @@ __global__ void __launch_bounds__(1024, 4) das_copies_kernel(BF_TABLE_PARAMS, KA
     if (tile_begin >= a.dir_end) return;
     const int tile_end = min(tile_begin + a.tile_dirs, a.dir_end);
 
-    const int rs = RS > 0 ? RS : a.row_stride, lead = RS > 0 ? kFixedLead : a.lead;
+    const int rs = RS > 0 ? RS : a.row_stride, lead = RS > 0 ? Geo<NSEG>::kLead : a.lead;
     const int mc = a.mic_chunk, M = a.n_mics, N = a.n_samples;
     const float* __restrict__ frame_sig = signals + (size_t)frame * a.m_total * N;
     float* __restrict__ img = images + (size_t)frame * a.image_stride;
     const int32_t* __restrict__ dig = reinterpret_cast<const int32_t*>(taps);
     const int slot_floats = A * 4 * rs;   // floats per staged mic
 
-    // Row of `signals` this wave stages in chunk c: mics[c*mc + wave].  Loaded once (lane c holds chunk c's row) so
-    // that the per-chunk prefetch below is a single independent load, not a load that waits for an index load.
-    int vmic = 0;
-    if (lane < a.n_chunks && lane * mc + wave < M) vmic = mics[lane * mc + wave];
-
-    // this thread's share of the staging: row `wave` of the chunk, quad `lane` (mc <= 16 = waves)
-    auto fetch = [&](int ch, int mcc) -> float4 {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (wave < mcc) {
-            const int mic = (ch < kWave) ? __builtin_amdgcn_readlane(vmic, ch) : mics[ch * mc + wave];
-            const float* src = frame_sig + (size_t)mic * N;
-            if ((N & 3) == 0) {
-                if (4 * lane < N) v = reinterpret_cast<const float4*>(src)[lane];
-            } else {
-                const int k = 4 * lane;
-                if (k < N) v.x = src[k];
-                if (k + 1 < N) v.y = src[k + 1];
-                if (k + 2 < N) v.z = src[k + 2];
-                if (k + 3 < N) v.w = src[k + 3];
+    // Rows of `signals` this wave stages: pair index pr = wave + 16 i  <->  chunk mic pr / NSEG, segment pr % NSEG.
+    // The mic ids of the first 64 chunks are loaded once (lane c holds chunk c's) so that the per-chunk prefetch is a
+    // single independent load, not a load that waits for an index load.
+    int vmic[SP];
+#pragma unroll
+    for (int i = 0; i < SP; ++i) {
+        const int cm = (wave + 16 * i) / NSEG;
+        vmic[i] = 0;
+        if (lane < a.n_chunks && cm < mc && lane * mc + cm < M) vmic[i] = mics[lane * mc + cm];
+    }
+    auto fetch = [&](int ch, int mcc, Staged (&st)[SP]) {
+#pragma unroll
+        for (int i = 0; i < SP; ++i) {
+            const int pr = wave + 16 * i, cm = pr / NSEG, seg = pr % NSEG;
+            st[i].v = make_float4(0.f, 0.f, 0.f, 0.f);
+            st[i].edge = 0.0f;
+            if (cm < mcc) {
+                const int mic = (ch < kWave) ? __builtin_amdgcn_readlane(vmic[i], ch) : mics[ch * mc + cm];
+                const float* src = frame_sig + (size_t)mic * N;
+                const int k = 4 * (64 * seg + lane);
+                if ((N & 3) == 0) {
+                    if (k < N) st[i].v = *reinterpret_cast<const float4*>(src + k);
+                } else {
+                    if (k < N) st[i].v.x = src[k];
+                    if (k + 1 < N) st[i].v.y = src[k + 1];
+                    if (k + 2 < N) st[i].v.z = src[k + 2];
+                    if (k + 3 < N) st[i].v.w = src[k + 3];
+                }
+                if constexpr (NSEG > 1) {
+                    // what DPP cannot reach: the three samples before the segment and the one after it
+                    const int ke = lane < 3 ? 256 * seg - 3 + lane : 256 * seg + 256;
+                    if ((lane < 3 || lane == 63) && ke >= 0 && ke < N) st[i].edge = src[ke];
+                }
             }
         }
-        return v;
+    };
+    auto stage = [&](int mcc, const Staged (&st)[SP]) {
+#pragma unroll
+        for (int i = 0; i < SP; ++i) {
+            const int pr = wave + 16 * i, cm = pr / NSEG, seg = pr % NSEG;
+            if (cm >= mcc) continue;
+            float* row0 = lds + cm * slot_floats;
+            const int col = lead + 256 * seg;
+            const float4 v = st[i].v;
+            float py = dpp_prev(v.y), pz = dpp_prev(v.z), pw = dpp_prev(v.w), nx = dpp_next(v.x);
+            float ey = 0.0f, ez = 0.0f, ew = 0.0f;
+            if constexpr (NSEG > 1) {
+                ey = lane_value(st[i].edge, 0); ez = lane_value(st[i].edge, 1); ew = lane_value(st[i].edge, 2);
+                const float en = lane_value(st[i].edge, 63);
+                if (lane == 0) { py = ey; pz = ez; pw = ew; }
+                if (lane == 63) nx = en;
+            }
+            write_copies(row0, rs, col, lane, v, py, pz, pw);
+            if constexpr (ALGO == ALGO_LERP) {
+                // D[i] = s[i+1] - s[i], the reference's own subtraction (lerp_and_sum.c:54); D[-1] stays 0 (prefix)
+                const float4 dq = make_float4(v.y - v.x, v.z - v.y, v.w - v.z, nx - v.w);
+                float dy = dpp_prev(dq.y), dz = dpp_prev(dq.z), dw = dpp_prev(dq.w);
+                if constexpr (NSEG > 1) {
+                    if (lane == 0 && seg > 0) { dy = ez - ey; dz = ew - ez; dw = v.x - ew; }
+                }
+                write_copies(row0 + 4 * rs, rs, col, lane, dq, dy, dz, dw);
+            }
+            if (seg == 0 && lane < (lead >> 2)) {   // the zero prefix (also wiped by the parked rows of the previous group)
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int c = 0; c < 4 * A; ++c) reinterpret_cast<float4*>(row0 + c * rs)[lane] = z;
+            }
+        }
     };
 
-    float4 staged = fetch(0, min(mc, M));
+    Staged staged[SP];
+    fetch(0, min(mc, M), staged);
     const char* lbase = reinterpret_cast<const char*>(lds) + 16 * lane;
 
     for (int g0 = tile_begin; g0 < tile_end; g0 += kGroup) {
         // v_pk_add_f32 / v_pk_fma_f32 keep the instruction count down (IEEE-identical to the scalar forms); the
-        // accumulators are two float2 register pairs matching the (x,y)/(z,w) halves of a quad read.
-        f32x2 acc[DPW][2];
+        // accumulators are float2 register pairs matching the (x,y)/(z,w) halves of a quad read.
+        f32x2 acc[DW][NSEG][2];
 #pragma unroll
-        for (int j = 0; j < DPW; ++j) { acc[j][0] = f32x2{0.0f, 0.0f}; acc[j][1] = f32x2{0.0f, 0.0f}; }
+        for (int j = 0; j < DW; ++j)
+#pragma unroll
+            for (int sg = 0; sg < NSEG; ++sg) { acc[j][sg][0] = f32x2{0.0f, 0.0f}; acc[j][sg][1] = f32x2{0.0f, 0.0f}; }
 
         for (int ch = 0; ch < a.n_chunks; ++ch) {
             const int m0 = ch * mc;
             const int mcc = min(mc, M - m0);
             __syncthreads();   // every wave is done with the previous contents (chunk reads or parked rows)
-            if (wave < mcc) {
-                float* row0 = lds + wave * slot_floats;
-                write_copies(row0, rs, lead, lane, staged);
-                if constexpr (ALGO == ALGO_LERP) {
-                    // D[i] = s[i+1] - s[i], the reference's own subtraction (lerp_and_sum.c:54); D[-1] stays 0 (prefix)
-                    const float nx = dpp_next(staged.x);
-                    const float4 dq = make_float4(staged.y - staged.x, staged.z - staged.y, staged.w - staged.z, nx - staged.w);
-                    write_copies(row0 + 4 * rs, rs, lead, lane, dq);
-                }
-            }
+            stage(mcc, staged);
             __syncthreads();
             {   // request the next chunk (or the next group's first) while this one is consumed
                 int ng0 = g0, nch = ch + 1;
                 if (nch == a.n_chunks) { nch = 0; ng0 = g0 + kGroup; }
-                if (ng0 < tile_end) staged = fetch(nch, min(mc, M - nch * mc));
+                if (ng0 < tile_end) fetch(nch, min(mc, M - nch * mc), staged);
             }
-            // One direction at a time, its staged mics in order, four mics' reads in flight.
-            auto directions = [&](auto full_c) {
-                constexpr bool FULL = decltype(full_c)::value;   // all 16 staged mics present: no per-mic conditionals
+            // One direction at a time, its staged mics in order, U mics x NSEG segments of reads in flight.
+            auto directions = [&](auto mcc_c) {
+                // MCC > 0: the chunk's mic count at compile time (a whole number of batches): straight-line code, no
+                // per-mic conditionals.  MCC == 0: any count, one uniform branch per batch.
+                constexpr int MCC = decltype(mcc_c)::value;
+                constexpr bool FULL = MCC > 0;
+                static_assert(MCC % U == 0, "whole batches");
 #pragma unroll
-                for (int j = 0; j < DPW; ++j) {
-                    const int d = g0 + wave * DPW + j;           // wave-uniform
+                for (int j = 0; j < DW; ++j) {
+                    const int d = g0 + wave * DW + j;           // wave-uniform
                     if (d >= tile_end) continue;
                     const size_t idx = (size_t)d * M + m0;
                     // 16 entries unconditionally (the tables carry 64 bytes of slack) so the loads merge into wide s_loads
@@ -777,58 +830,107 @@ __global__ void __launch_bounds__(1024, 4) das_copies_kernel(BF_TABLE_PARAMS, KA
                         hh[m] = 0.0f;
                         if constexpr (ALGO == ALGO_LERP) hh[m] = frac[idx + m];
                     }
-                    f32x2(&ac)[2] = acc[j];
-#pragma unroll
-                    for (int m4 = 0; m4 < 16; m4 += 4) {
-                        if (!FULL && m4 >= mcc) break;
-                        float4 S[4], Dq[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            // a partial chunk re-reads mic 0's row for the missing mics and drops the result
-                            const int eo = (FULL || m4 + u < mcc) ? e[m4 + u] : e[0];
-                            const char* sp = lbase + eo;
-                            S[u] = *reinterpret_cast<const float4*>(sp);
-                            if constexpr (ALGO == ALGO_LERP) Dq[u] = *reinterpret_cast<const float4*>(sp + 16 * rs);   // D copies: 4 rows on
+                    auto consume = [&](const float4& Sq, const float4& Dv, float h, f32x2 (&ac)[2]) {
+                        const f32x2 S01{Sq.x, Sq.y}, S23{Sq.z, Sq.w};
+                        if constexpr (ALGO == ALGO_PAD) {
+                            // pad_and_sum.c:41-47   out[k] += s[k - p]
+                            ac[0] += S01; ac[1] += S23;
+                        } else {
+                            // lerp_and_sum.c:50-56  out[k] += s[i] + h * (s[i+1] - s[i]),  i = k - p - 1
+                            const f32x2 h2{h, h}, D01{Dv.x, Dv.y}, D23{Dv.z, Dv.w};
+                            ac[0] += __builtin_elementwise_fma(h2, D01, S01);
+                            ac[1] += __builtin_elementwise_fma(h2, D23, S23);
                         }
+                    };
+                    if constexpr (FULL) {
+                        // software pipeline over the (mic, segment) units of this direction: R units' reads in flight,
+                        // each consumed unit's registers are refilled at once
+                        constexpr int R = 4, UNITS = MCC * NSEG;
+                        float4 S[R], Dq[R];
+                        auto issue = [&](int i, int slot) {
+                            const char* sp = lbase + e[i / NSEG] + 1024 * (i % NSEG);
+                            S[slot] = *reinterpret_cast<const float4*>(sp);
+                            if constexpr (ALGO == ALGO_LERP) Dq[slot] = *reinterpret_cast<const float4*>(sp + 16 * rs);   // D copies: 4 rows on
+                        };
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            if (!FULL && m4 + u >= mcc) break;
-                            const f32x2 S01{S[u].x, S[u].y}, S23{S[u].z, S[u].w};
-                            if constexpr (ALGO == ALGO_PAD) {
-                                // pad_and_sum.c:41-47   out[k] += s[k - p]
-                                ac[0] += S01; ac[1] += S23;
-                            } else {
-                                // lerp_and_sum.c:50-56  out[k] += s[i] + h * (s[i+1] - s[i]),  i = k - p - 1
-                                const f32x2 h2{hh[m4 + u], hh[m4 + u]}, D01{Dq[u].x, Dq[u].y}, D23{Dq[u].z, Dq[u].w};
-                                ac[0] += __builtin_elementwise_fma(h2, D01, S01);
-                                ac[1] += __builtin_elementwise_fma(h2, D23, S23);
+                        for (int i = 0; i < R; ++i) issue(i, i);
+#pragma unroll
+                        for (int i = 0; i < UNITS; ++i) {
+                            consume(S[i % R], Dq[i % R], hh[i / NSEG], acc[j][i % NSEG]);
+                            if (i + R < UNITS) issue(i + R, i % R);
+                        }
+                    } else {
+#pragma unroll
+                        for (int mb = 0; mb < 16; mb += U) {
+                            if (mb >= mcc) break;
+                            float4 S[U][NSEG], Dq[U][NSEG];
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                // a partial batch re-reads mic 0's row for the missing mics and drops the result
+                                const int eo = (mb + u < mcc) ? e[mb + u] : e[0];
+                                const char* sp = lbase + eo;
+#pragma unroll
+                                for (int sg = 0; sg < NSEG; ++sg) {
+                                    S[u][sg] = *reinterpret_cast<const float4*>(sp + 1024 * sg);
+                                    if constexpr (ALGO == ALGO_LERP) Dq[u][sg] = *reinterpret_cast<const float4*>(sp + 16 * rs + 1024 * sg);
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                if (mb + u >= mcc) break;
+#pragma unroll
+                                for (int sg = 0; sg < NSEG; ++sg) consume(S[u][sg], Dq[u][sg], hh[mb + u], acc[j][sg]);
                             }
                         }
                     }
                 }
             };
-            if (mcc == 16) directions(std::true_type{}); else directions(std::false_type{});
+            // N <= 256: the chunk sizes the planner picks get straight-line code.  With more segments the 64 accumulator
+            // registers leave no room for the deeper read pipelining that buys (it spills), so only the branchy form.
+            if constexpr (NSEG == 1) {
+                if (mcc == 16) directions(std::integral_constant<int, 16>{});
+                else if (mcc == 8) directions(std::integral_constant<int, 8>{});
+                else directions(std::integral_constant<int, 0>{});
+            } else {
+                directions(std::integral_constant<int, 0>{});
+            }
         }
 
-        // ---- k-ordered mean power (pad_and_sum.c:120-128): every wave parks the squared means of its 8 directions
-        // (row = direction within the group; the rows alias the chunk buffer), then two waves run the sequential
-        // sums with one direction per lane: 64 chains per instruction instead of 8, and coalesced image stores.
-        __syncthreads();
+        // ---- k-ordered mean power (pad_and_sum.c:120-128): the waves park the squared means of their directions
+        // (row = direction; the rows alias the chunk buffer; a.pbw waves at a time when a group's rows outgrow it),
+        // then one direction per lane runs the sequential sum: 64 chains per instruction, coalesced image stores.
+        const int pw_waves = NSEG == 1 ? kWaves : a.pbw;   // N <= 256: the planner sizes LDS for the whole group's rows
+        for (int w0 = 0; w0 < kWaves; w0 += pw_waves) {
+            __syncthreads();
+            if (wave >= w0 && wave < w0 + pw_waves) {
+                // mean over the mics: a power-of-two count multiplies (exact), anything else divides like the reference;
+                // two separate code paths so that the division sequence is never executed speculatively
+                auto park = [&](auto mul_c) {
 #pragma unroll
-        for (int j = 0; j < DPW; ++j) {
-            const f32x2 a0 = acc[j][0], a1 = acc[j][1];
-            const float o0 = a.n_is_pow2 ? a0.x * a.inv_n : a0.x / (float)M;
-            const float o1 = a.n_is_pow2 ? a0.y * a.inv_n : a0.y / (float)M;
-            const float o2 = a.n_is_pow2 ? a1.x * a.inv_n : a1.x / (float)M;
-            const float o3 = a.n_is_pow2 ? a1.y * a.inv_n : a1.y / (float)M;
-            reinterpret_cast<float4*>(lds + (wave * DPW + j) * kParkStride)[lane] = make_float4(o0 * o0, o1 * o1, o2 * o2, o3 * o3);
-        }
-        __syncthreads();
-        if (wave < kGroup / kWave) {
-            const int g = wave * kWave + lane;
-            const int d = g0 + g;
-            if (d < tile_end) {
-                const float* row = lds + g * kParkStride;
+                    for (int j = 0; j < DW; ++j) {
+                        float* row = lds + ((wave - w0) * DW + j) * kPark;
+#pragma unroll
+                        for (int sg = 0; sg < NSEG; ++sg) {
+                            const f32x2 a0 = acc[j][sg][0], a1 = acc[j][sg][1];
+                            float o0, o1, o2, o3;
+                            if constexpr (decltype(mul_c)::value) {
+                                o0 = a0.x * a.inv_n; o1 = a0.y * a.inv_n; o2 = a1.x * a.inv_n; o3 = a1.y * a.inv_n;
+                            } else {
+                                float fm = (float)M;
+                                asm volatile("" : "+v"(fm));   // not speculatable: keeps this path behind its branch
+                                o0 = a0.x / fm; o1 = a0.y / fm; o2 = a1.x / fm; o3 = a1.y / fm;
+                            }
+                            reinterpret_cast<float4*>(row + 256 * sg)[lane] = make_float4(o0 * o0, o1 * o1, o2 * o2, o3 * o3);
+                        }
+                    }
+                };
+                if (__builtin_expect(a.n_is_pow2, 1)) park(std::true_type{}); else park(std::false_type{});
+            }
+            __syncthreads();
+            const int g = wave * kWave + lane;            // parked row of this lane
+            const int d = g0 + w0 * DW + g;
+            if (g < pw_waves * DW && d < tile_end) {
+                const float* row = lds + g * kPark;
                 const float4* row4 = reinterpret_cast<const float4*>(row);
                 float sum = 0.0f;
                 int k = 0;
@@ -860,20 +962,22 @@ hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, in
         hipLaunchKernelGGL(kernel, grid, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole, L.tab.frac, L.tab.taps, a);
         return hipGetLastError();
     };
-    if constexpr (NC == 4 && (ALGO == ALGO_PAD || ALGO == ALGO_LERP)) {
+    if constexpr (NC >= 4 && (ALGO == ALGO_PAD || ALGO == ALGO_LERP)) {
         if (plan.layout == 2) {
             if (L.tab.digest == nullptr) return hipErrorInvalidValue;   // launch_digest first
+            constexpr int NSEG = NC / 4;
+            using G = copies::Geo<NSEG>;
+            auto kernel = plan.row_stride == G::kRs && plan.lead == G::kLead ? copies::das_copies_kernel<ALGO, NSEG, G::kRs>
+                                                                             : copies::das_copies_kernel<ALGO, NSEG, 0>;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
+            if (e != hipSuccess) return e;
             // the digest rides in the (unused) taps slot
-            auto go2 = [&](auto kernel) -> hipError_t {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
-                if (e != hipSuccess) return e;
-                hipLaunchKernelGGL(kernel, grid, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole, L.tab.frac,
-                                   reinterpret_cast<const float*>(L.tab.digest), a);
-                return hipGetLastError();
-            };
-            return plan.row_stride == copies::kFixedRs && plan.lead == copies::kFixedLead ? go2(copies::das_copies_kernel<ALGO, copies::kFixedRs>)
-                                                                                          : go2(copies::das_copies_kernel<ALGO, 0>);
+            hipLaunchKernelGGL(kernel, grid, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole, L.tab.frac,
+                               reinterpret_cast<const float*>(L.tab.digest), a);
+            return hipGetLastError();
         }
+    }
+    if constexpr (NC == 4 && (ALGO == ALGO_PAD || ALGO == ALGO_LERP)) {
         if (plan.quad) {
             switch (plan.dpw) {
                 case 1: return go(das_mimo_kernel<ALGO, 4, 1, true>);
@@ -982,26 +1086,36 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
         p.mic_chunk = mc; p.n_chunks = (L.n_mics + mc - 1) / mc;
         p.dpw = p.n_chunks > 1 ? 4 : 1;
     }
-    // Layout for pad / lerp at N <= 256: 2 = shifted copies (default), 1 = quad + DPP + scalar branch, 0 = strided.
-    const bool small_block = p.nc == 4 && (L.algo == ALGO_PAD || L.algo == ALGO_LERP);
-    p.layout = small_block ? (L.force_layout >= 0 ? L.force_layout : 2) : 0;
+    // Layout for pad / lerp at 128 < N <= 1024: 2 = shifted copies (default), 0 = strided; N <= 256 only: 1 = quad + DPP.
+    const bool copies_ok = p.nc >= 4 && (L.algo == ALGO_PAD || L.algo == ALGO_LERP);
+    p.layout = copies_ok ? (L.force_layout >= 0 ? L.force_layout : 2) : 0;
+    if (p.layout == 1 && p.nc != 4) p.layout = 0;
     p.quad = p.layout == 1 ? 1 : 0;
     if (p.layout == 2) {
-        const int arrays = (L.algo == ALGO_LERP) ? 2 : 1;
+        const int nseg = p.nc / 4, arrays = (L.algo == ALGO_LERP) ? 2 : 1;
+        const int fixed_lead = nseg == 1 ? copies::Geo<1>::kLead : copies::Geo<4>::kLead;   // Geo<2> == Geo<4> here
+        const int dw = nseg == 4 ? copies::Geo<4>::kDw : copies::Geo<1>::kDw;               // Geo<2> == Geo<1> here
         p.lead = round_up(L.tab.max_whole + 2, 4);       // lerp folds its extra sample into the delay (p + 1)
-        if (p.lead <= copies::kFixedLead && !(L.debug & 2)) p.lead = copies::kFixedLead;   // compile-time row stride
-        p.row_stride = p.lead + 256;
+        if (p.lead <= fixed_lead && !(L.debug & 2)) p.lead = fixed_lead;   // compile-time row stride
+        p.row_stride = p.lead + nseg * 256;
         const size_t slot_bytes = (size_t)arrays * 4 * p.row_stride * sizeof(float);
+        // a chunk: as many mics as fit beside nothing else in 156 KiB, at most 16 (one s_load of table entries) and at
+        // most what the 16 waves stage in one go (one (mic, segment) pair each; two for pad with several segments)
+        const int stage_pairs = 16 * ((nseg > 1 && L.algo == ALGO_PAD) ? 2 : 1);
         int mc = (int)((size_t)156 * 1024 / slot_bytes);
-        mc = mc >= 16 ? 16 : mc >= 8 ? 8 : mc;
+        if (mc > stage_pairs / nseg) mc = stage_pairs / nseg;
+        mc = mc >= 16 ? 16 : mc >= 8 ? 8 : mc >= 4 ? 4 : mc >= 2 ? 2 : mc;
         if (mc < 1) return fail(3);
         if (mc > L.n_mics) mc = L.n_mics;
         p.mic_chunk = mc; p.n_chunks = (L.n_mics + mc - 1) / mc;
-        p.waves = copies::kWaves; p.dpw = copies::kDpw; p.pbw = copies::kDpw; p.srow = copies::kParkStride;
+        p.waves = copies::kWaves; p.dpw = dw; p.srow = nseg * 256 + 4;
         p.scratch_off = 0;
-        const size_t park = (size_t)copies::kGroup * copies::kParkStride * sizeof(float);
         const size_t buf = slot_bytes * (size_t)mc;
-        p.lds_bytes = buf > park ? buf : park;
+        const size_t wave_rows = (size_t)dw * p.srow * sizeof(float);          // the parked rows of one wave
+        p.lds_bytes = buf > 2 * wave_rows ? buf : 2 * wave_rows;
+        if (nseg == 1 && p.lds_bytes < 16 * wave_rows) p.lds_bytes = 16 * wave_rows;   // N <= 256: the whole group parks at once
+        int pw = (int)(p.lds_bytes / wave_rows);                                 // waves that park together (power of two)
+        p.pbw = pw >= 16 ? 16 : pw >= 8 ? 8 : pw >= 4 ? 4 : 2;
     }
     if (p.layout != 2) {
         p.scratch_off = round_up(p.mic_chunk * p.row_stride, 4);

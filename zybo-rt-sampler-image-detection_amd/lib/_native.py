@@ -7,7 +7,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbeamformer_hip.so")
+# $BF_NATIVE_LIB: another build of the same library (kernel A/B runs); the default is the in-tree build
+LIB_PATH = os.environ.get("BF_NATIVE_LIB") or os.path.join(_HERE, "libbeamformer_hip.so")
 
 
 class BeamformerError(RuntimeError):
