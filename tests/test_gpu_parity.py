@@ -118,6 +118,11 @@ EDGE = [
     (300, 280,  256,  4,  3,  8,  47.0),   # mic block larger than LDS: chunked staging, DPW accumulators
     (2,     1,  128,  1,  1,  8,   0.0),   # 1x1 grid, one mic, zero delay
     (32,   32,  256,  4,  4, 16,   9.0),   # 16 taps (two AVX blocks in the vectorized FIR order)
+    (16,   16,  256,  3,  3,  8, 255.5),   # delays up to the block length at N = 256: zero prefix longer than one wave's quads
+    (24,   20,  512,  5,  4,  8,  60.0),   # two 256-sample segments in the shifted-copies kernel
+    (8,     8,  258,  2,  2,  8,  10.0),   # second segment almost empty, N not a multiple of 4 (scalar staging loads)
+    (12,    9,  450,  3,  3,  8, 200.0),   # delays past the fixed-stride prefix: run-time row stride, partial chunk
+    (40,   33, 1024,  3,  2,  8, 300.0),   # four segments, several chunks (pad stages two (mic, segment) pairs per wave)
 ]
 
 

@@ -777,10 +777,12 @@ __global__ void __launch_bounds__(1024, 4) das_copies_kernel(BF_TABLE_PARAMS, KA
                 }
                 write_copies(row0 + 4 * rs, rs, col, lane, dq, dy, dz, dw);
             }
-            if (seg == 0 && lane < (lead >> 2)) {   // the zero prefix (also wiped by the parked rows of the previous group)
+            if (seg == 0) {   // the zero prefix (also wiped by the parked rows of the previous group); lead can exceed 256
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int q = lane; q < (lead >> 2); q += kWave) {
 #pragma unroll
-                for (int c = 0; c < 4 * A; ++c) reinterpret_cast<float4*>(row0 + c * rs)[lane] = z;
+                    for (int c = 0; c < 4 * A; ++c) reinterpret_cast<float4*>(row0 + c * rs)[q] = z;
+                }
             }
         }
     };
