@@ -93,3 +93,48 @@ def test_gpu_mvdr_matches_float64_oracle(native):
         assert np.max(np.abs(dgot - dwant)) <= TOL_OF_PEAK * dwant.max()
     finally:
         C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y = old
+
+
+GEMM_SHAPES = [
+    # rows(I) mics(K) dirs(J) bins   what it exercises
+    (150,  37,  45,  9),    # 5 row tiles -> 2 row groups of 3, odd K (half-empty last MFMA step), ragged column tile
+    (33,  100, 200,  5),    # 2 panels of K, second partial; 2 row tiles, second almost empty
+    (190,  64, 333, 23),    # the bench shape in miniature: several bin groups + the plane reduction
+    (8,   130,  64,  3),    # K > 128: three panels
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("I,K,J,B", GEMM_SHAPES)
+def test_gpu_bin_reducing_gemms_match_numpy(native, I, K, J, B):
+    """bf_fd_das_power_device / bf_fd_mvdr_power_device on random complex operands against complex128 NumPy:
+    P[f, d] = sum_b |sum_k X[b,k,f] A[b,k,d]|^2   and   P[d] = sum_b 1 / sum_i |sum_k L[b,k,i] conj(A[b,k,d])|^2."""
+    import torch
+    rng = np.random.default_rng(I * 1000 + K)
+    x = (rng.standard_normal((B, K, I)) + 1j * rng.standard_normal((B, K, I))).astype(np.complex64)
+    a = np.exp(1j * rng.uniform(0, 2 * np.pi, (B, K, J))).astype(np.complex64)
+    dev = lambda v: torch.from_numpy(np.ascontiguousarray(v)).cuda()
+    xr, xi, ar, ai = dev(x.real), dev(x.imag), dev(a.real), dev(a.imag)
+    p = torch.full((I, J), float("nan"), dtype=torch.float32, device="cuda")
+    assert native.lib.bf_fd_das_power_device(xr.data_ptr(), xi.data_ptr(), ar.data_ptr(), ai.data_ptr(), I, K, J, B, p.data_ptr(), None) == 0, native.check()
+    want = (np.abs(np.einsum("bki,bkj->bij", x.astype(np.complex128), a.astype(np.complex128))) ** 2).sum(0)
+    got = p.double().cpu().numpy()
+    assert np.max(np.abs(got - want)) <= TOL_OF_PEAK * want.max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,J,B", [(37, 45, 9), (64, 333, 23), (100, 70, 4), (128, 200, 6)])
+def test_gpu_mvdr_quadratic_form_matches_numpy(native, M, J, B):
+    """bf_fd_mvdr_power_device on a random (transposed) triangular-inverse stand-in L[b, k, i]:
+    P[d] = sum_b 1 / sum_i |sum_k L[b,k,i] conj(A[b,k,d])|^2  against complex128 NumPy."""
+    import torch
+    rng = np.random.default_rng(M)
+    l = (rng.standard_normal((B, M, M)) + 1j * rng.standard_normal((B, M, M))).astype(np.complex64)
+    a = np.exp(1j * rng.uniform(0, 2 * np.pi, (B, M, J))).astype(np.complex64)
+    dev = lambda v: torch.from_numpy(np.ascontiguousarray(v)).cuda()
+    lr, li, ar, ai = dev(l.real), dev(l.imag), dev(a.real), dev(a.imag)
+    q = torch.full((J,), float("nan"), dtype=torch.float32, device="cuda")
+    assert native.lib.bf_fd_mvdr_power_device(lr.data_ptr(), li.data_ptr(), ar.data_ptr(), ai.data_ptr(), M, J, B, q.data_ptr(), None) == 0, native.check()
+    y = np.einsum("bki,bkj->bij", l.astype(np.complex128), np.conj(a.astype(np.complex128)))
+    want = (1.0 / (np.abs(y) ** 2).sum(1)).sum(0)
+    assert np.max(np.abs(q.double().cpu().numpy() - want) / want) <= 1e-4

@@ -75,6 +75,7 @@ struct State {
     // scratch for the host-pointer entry points
     DevBuf<float> d_frame, d_image, d_out, d_init, d_one_taps, d_one_frac;
     DevBuf<int32_t> d_mics, d_one_whole;
+    DevBuf<float> fd_work;               // partial planes of the bin-reducing GEMMs (bf::fd_workspace_floats)
     std::vector<int> mics_host;          // what d_mics currently holds
     std::vector<float> published;        // bf_publish_frame / get_data
     std::vector<int> disabled_mics;      // get_data's dead-microphone rows
@@ -888,7 +889,9 @@ int bf_fd_das_power_device(const float* d_xre_mf, const float* d_xim_mf, const f
                            int n_bins, float* d_power, void* stream)
 {
     FD_ENTER(d_xre_mf && d_xim_mf && d_are && d_aim && d_power && frames > 0 && n_mics > 0 && n_dirs > 0 && n_bins > 0, "bf_fd_das_power_device")
-    return HIP_OK(bf::launch_fd_das_power(d_xre_mf, d_xim_mf, d_are, d_aim, frames, n_mics, n_dirs, n_bins, d_power, st)) ? 0 : -1;
+    const size_t work = bf::fd_workspace_floats(frames, n_dirs, n_bins);
+    if (!HIP_OK(s.fd_work.reserve(work))) return -1;
+    return HIP_OK(bf::launch_fd_das_power(d_xre_mf, d_xim_mf, d_are, d_aim, frames, n_mics, n_dirs, n_bins, d_power, s.fd_work.p, s.fd_work.cap, st)) ? 0 : -1;
 }
 
 int bf_fd_covariance_device(const float* d_xre_fm, const float* d_xim_fm, int frames, int n_mics, int n_bins, float* d_rre, float* d_rim, void* stream)
@@ -910,7 +913,9 @@ int bf_fd_mvdr_power_device(const float* d_lire_t, const float* d_liim_t, const 
 {
     FD_ENTER(d_lire_t && d_liim_t && d_are && d_aim && d_power && n_mics > 0 && n_dirs > 0 && n_bins > 0, "bf_fd_mvdr_power_device")
     if (n_mics > 128) { set_error("bf_fd_mvdr_power_device: %d mics; at most 128", n_mics); return -1; }
-    return HIP_OK(bf::launch_fd_mvdr_power(d_lire_t, d_liim_t, d_are, d_aim, n_mics, n_dirs, n_bins, d_power, st)) ? 0 : -1;
+    const size_t work = bf::fd_workspace_floats(1, n_dirs, n_bins);
+    if (!HIP_OK(s.fd_work.reserve(work))) return -1;
+    return HIP_OK(bf::launch_fd_mvdr_power(d_lire_t, d_liim_t, d_are, d_aim, n_mics, n_dirs, n_bins, d_power, s.fd_work.p, s.fd_work.cap, st)) ? 0 : -1;
 }
 
 // ---------------------------------------------------------------- detector post-processing

@@ -95,13 +95,16 @@ hipError_t launch_power_center(const float* d_power, int frames, int rows, int c
 hipError_t launch_fd_steering(const double* d_tau, const double* d_freq, int n_dirs, int n_mics, int n_bins, float* d_are, float* d_aim, hipStream_t stream);
 hipError_t launch_fd_dft(const float* d_frames, const int32_t* d_mics, int m_total, int n_samples, int n_frames, int n_mics, int bin_lo, int n_bins,
                          float* xre_mf, float* xim_mf, float* xre_fm, float* xim_fm, hipStream_t stream);
+// Workspace (floats) that lets the two bin-reducing GEMMs split the bins over several workgroup groups (optional: without
+// it they run one group).  n_rows = frames for the delay-and-sum power, 1 for MVDR.
+size_t fd_workspace_floats(int n_rows, int n_dirs, int n_bins);
 hipError_t launch_fd_das_power(const float* xre_mf, const float* xim_mf, const float* are, const float* aim, int n_frames, int n_mics, int n_dirs,
-                               int n_bins, float* d_power, hipStream_t stream);
+                               int n_bins, float* d_power, float* d_work, size_t work_floats, hipStream_t stream);
 hipError_t launch_fd_covariance(const float* xre_fm, const float* xim_fm, int n_frames, int n_mics, int n_bins, float* rre, float* rim, hipStream_t stream);
 hipError_t launch_fd_cholesky_inverse(const float* rre, const float* rim, int n_mics, int n_bins, float loading, float* lire_t, float* liim_t,
                                       int* d_status, hipStream_t stream);
 hipError_t launch_fd_mvdr_power(const float* lire_t, const float* liim_t, const float* are, const float* aim, int n_mics, int n_dirs, int n_bins,
-                                float* d_power, hipStream_t stream);
+                                float* d_power, float* d_work, size_t work_floats, hipStream_t stream);
 
 // detector post-processing (nms_kernels.hip): YOLOv5 head decode + confidence filter, greedy NMS over score-sorted candidates
 hipError_t launch_yolo_decode(const void* const raw[3], const int hs[3], const int ws[3], const int strides[3], const float* anchors,

@@ -125,6 +125,159 @@ __global__ void __launch_bounds__(256) cgemm_kernel(GemmArgs g)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The two big GEMMs (phase-steer DAS power, MVDR quadratic form) reduce over the bins, so they get a kernel that keeps
+// the matrix cores fed: a wave owns one 32-column tile of B (32 directions) and RT row tiles of A, and walks its share
+// of the bins.  Per bin it loads a 64-deep panel of B into registers once (64 VGPRs: re/im x 32 k-steps), then per row
+// tile a panel of A (64 VGPRs) and issues 128 back-to-back MFMAs (4 real MFMAs per complex k-step).  Two such waves
+// per SIMD (<= 256 VGPRs each) hide each other's panel loads.  The 4 waves of a workgroup take bins b0+w, b0+w+4, ...
+// and are summed in wave order through LDS; bin groups (blockIdx.y) write partial planes that reduce_planes_kernel
+// sums in group order -- no atomics, bit-reproducible.
+struct Panel { float re[32], im[32]; };
+
+// One 64-deep panel in MFMA operand order: step s2 holds row k0 + 2 s2 + (lane >> 5), column (lane & 31) of the tile.
+// `re` / `im` are wave-uniform plane pointers (batch applied), `voff` the lane's element offset (lk * ld + column), so
+// every load is "scalar base + 32-bit lane offset" and costs no vector address arithmetic.
+__device__ __forceinline__ void load_panel(Panel& p, const float* __restrict__ re, const float* __restrict__ im, int ld, int k0, int K, int lk,
+                                           int voff, bool ok, bool conj)
+{
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2) { p.re[s2] = 0.0f; p.im[s2] = 0.0f; }
+    if (ok) {
+        if (k0 + 64 <= K) {                      // whole panel in range: straight loads
+#pragma unroll
+            for (int s2 = 0; s2 < 32; ++s2) {
+                const size_t row = (size_t)(k0 + 2 * s2) * (size_t)ld;     // uniform
+                p.re[s2] = (re + row)[voff];
+                p.im[s2] = (im + row)[voff];
+            }
+        } else {
+#pragma unroll
+            for (int s2 = 0; s2 < 32; ++s2) {
+                const int k = k0 + 2 * s2;       // uniform
+                if (k + lk < K) {
+                    const size_t row = (size_t)k * (size_t)ld;
+                    p.re[s2] = (re + row)[voff];
+                    p.im[s2] = (im + row)[voff];
+                }
+            }
+        }
+        if (conj) {
+#pragma unroll
+            for (int s2 = 0; s2 < 32; ++s2) p.im[s2] = -p.im[s2];
+        }
+    }
+}
+
+template <int EPI, int RT>
+__global__ void __launch_bounds__(256, 2) cgemm_bins_kernel(GemmArgs g, int row_groups, int bins_per_group)
+{
+    static_assert(EPI == EPI_POWER || EPI == EPI_MVDR, "bin-reducing epilogues");
+    extern __shared__ float red[];              // [4 waves][RT * 16][64 lanes] (POWER) or [4][32] (MVDR)
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int rg = (int)(blockIdx.x % (unsigned)row_groups);     // row group fastest: the groups that share a B tile run together
+    const int j0 = (int)(blockIdx.x / (unsigned)row_groups) * 32;
+    const int b0 = blockIdx.y * bins_per_group, b1 = min(b0 + bins_per_group, g.batch);
+    const bool bj_ok = j0 + li < g.J;
+    const bool single = g.K <= 64;              // one panel: B is loaded once per bin and shared by the row tiles
+    const int row_tiles = (EPI == EPI_MVDR) ? (g.I + 31) / 32 : RT;
+    const int rt_base = (EPI == EPI_MVDR) ? 0 : rg * RT;
+
+    f32x16 acc_p[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_p[t][r] = 0.0f;
+    float inv_sum = 0.0f;
+
+    const int b_voff = lk * g.J + j0 + li;
+    for (int b = b0 + wave; b < b1; b += 4) {
+        const float* bre = g.b_re + ((size_t)b * g.K) * g.J;      // wave-uniform plane pointers
+        const float* bim = g.b_im + ((size_t)b * g.K) * g.J;
+        const float* are = g.a_re + ((size_t)b * g.K) * g.I;
+        const float* aim = g.a_im + ((size_t)b * g.K) * g.I;
+        Panel Bp;
+        if (single) load_panel(Bp, bre, bim, g.J, 0, g.K, lk, b_voff, bj_ok, g.conj_b != 0);
+        float colsum = 0.0f;
+
+        auto row_tile = [&](int rt, f32x16* accp) {
+            const int ib = (rt_base + rt) * 32;
+            const bool a_ok = ib + li < g.I;
+            const int a_voff = lk * g.I + ib + li;
+            f32x16 cre, cim;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { cre[r] = 0.0f; cim[r] = 0.0f; }
+            for (int k0 = 0; k0 < g.K; k0 += 64) {
+                Panel Ap;
+                load_panel(Ap, are, aim, g.I, k0, g.K, lk, a_voff, a_ok, false);
+                if (!single) load_panel(Bp, bre, bim, g.J, k0, g.K, lk, b_voff, bj_ok, g.conj_b != 0);
+#pragma unroll
+                for (int s2 = 0; s2 < 32; ++s2) {
+                    // (xr + j xi)(yr + j yi)
+                    cre = __builtin_amdgcn_mfma_f32_32x32x2f32(Ap.re[s2], Bp.re[s2], cre, 0, 0, 0);
+                    cim = __builtin_amdgcn_mfma_f32_32x32x2f32(Ap.re[s2], Bp.im[s2], cim, 0, 0, 0);
+                    cre = __builtin_amdgcn_mfma_f32_32x32x2f32(-Ap.im[s2], Bp.im[s2], cre, 0, 0, 0);
+                    cim = __builtin_amdgcn_mfma_f32_32x32x2f32(Ap.im[s2], Bp.re[s2], cim, 0, 0, 0);
+                }
+            }
+            if constexpr (EPI == EPI_POWER) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) (*accp)[r] += cre[r] * cre[r] + cim[r] * cim[r];
+            } else {
+                float sq = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sq += cre[r] * cre[r] + cim[r] * cim[r];   // rows outside I were zero operands
+                colsum += sq;
+            }
+        };
+        if constexpr (EPI == EPI_POWER) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t) row_tile(t, &acc_p[t]);
+        } else {
+            for (int t = 0; t < row_tiles; ++t) row_tile(t, nullptr);
+            colsum += __shfl_xor(colsum, 32, 64);      // the other half of the rows of this column
+            inv_sum += 1.0f / colsum;
+        }
+    }
+
+    // ---- the 4 waves' partial sums, added in wave order
+    if constexpr (EPI == EPI_POWER) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave * RT + t) * 16 + r) * 64 + lane] = acc_p[t][r];
+        __syncthreads();
+        float* out = g.out0 + (size_t)blockIdx.y * g.I * g.J;
+        const int col = j0 + li;
+        for (int e = wave; e < RT * 16; e += 4) {            // entry e = (row tile, register)
+            const int t = e >> 4, r = e & 15;
+            float v = red[((0 * RT + t) * 16 + r) * 64 + lane];
+            v += red[((1 * RT + t) * 16 + r) * 64 + lane];
+            v += red[((2 * RT + t) * 16 + r) * 64 + lane];
+            v += red[((3 * RT + t) * 16 + r) * 64 + lane];
+            const int row = (rt_base + t) * 32 + acc_row(r, lane);
+            if (row < g.I && col < g.J) out[(size_t)row * g.J + col] = v;
+        }
+    } else {
+        if (lane < 32) red[wave * 32 + lane] = inv_sum;
+        __syncthreads();
+        if (wave == 0 && lane < 32 && j0 + li < g.J)
+            g.out0[(size_t)blockIdx.y * g.J + j0 + li] = ((red[lane] + red[32 + lane]) + red[64 + lane]) + red[96 + lane];
+    }
+}
+
+// out[i] = sum over the planes, in plane order
+__global__ void __launch_bounds__(256) reduce_planes_kernel(const float* __restrict__ planes, int n_planes, size_t plane, float* __restrict__ out)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x) {
+        float v = planes[i];
+        for (int p = 1; p < n_planes; ++p) v += planes[(size_t)p * plane + i];
+        out[i] = v;
+    }
+}
+
 // X[k][.] = sum_n s[n] exp(-2 pi j k n / N) for the bins [bin_lo, bin_hi) (numpy.fft.rfft semantics), direct DFT with an
 // LDS twiddle table.  One workgroup per (frame, mic); thread t owns bin bin_lo + t.  Writes both operand layouts the
 // GEMMs need: [K][M][F] (mic-major, frames contiguous) and [K][F][M] (frame-major, mics contiguous).
@@ -269,11 +422,62 @@ hipError_t launch_fd_dft(const float* d_frames, const int32_t* d_mics, int m_tot
     return hipGetLastError();
 }
 
+namespace {
+
+// Bin groups so that the launch fills the chip a few times over (two 4-wave workgroups per CU) while every wave keeps >= 2 bins.
+int bin_groups(int col_tiles, int row_groups, int n_bins)
+{
+    const int per_wave_cap = (n_bins + 7) / 8;                    // at least 2 bins per wave, 8 per workgroup
+    int want = (1536 + col_tiles * row_groups - 1) / (col_tiles * row_groups);
+    if (want > per_wave_cap) want = per_wave_cap;
+    return want < 1 ? 1 : want;
+}
+
+template <int EPI, int RT>
+hipError_t run_bins(const GemmArgs& g0, int row_groups, float* d_work, size_t work_floats, size_t plane, hipStream_t stream)
+{
+    GemmArgs g = g0;
+    const int col_tiles = (g.J + 31) / 32;
+    int groups = bin_groups(col_tiles, row_groups, g.batch);
+    if (groups > 1 && (d_work == nullptr || work_floats < (size_t)groups * plane)) groups = 1;   // no workspace: one group, direct output
+    const int per_group = (g.batch + groups - 1) / groups;
+    groups = (g.batch + per_group - 1) / per_group;
+    float* final_out = g.out0;
+    if (groups > 1) g.out0 = d_work;
+    const size_t lds = (EPI == EPI_POWER) ? (size_t)4 * RT * 16 * 64 * sizeof(float) : (size_t)4 * 32 * sizeof(float);
+    auto kernel = cgemm_bins_kernel<EPI, RT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(col_tiles * row_groups), (unsigned)groups), dim3(256), lds, stream, g, row_groups, per_group);
+    e = hipGetLastError();
+    if (e != hipSuccess || groups == 1) return e;
+    hipLaunchKernelGGL(reduce_planes_kernel, dim3(1024), dim3(256), 0, stream, d_work, groups, plane, final_out);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+size_t fd_workspace_floats(int n_rows, int n_dirs, int n_bins)
+{
+    // the most bin groups run_bins can choose, times one output plane (n_rows = frames for the DAS power, 1 for MVDR)
+    return (size_t)((n_bins + 7) / 8) * (size_t)n_rows * (size_t)n_dirs;
+}
+
 hipError_t launch_fd_das_power(const float* xre_mf, const float* xim_mf, const float* are, const float* aim, int n_frames, int n_mics, int n_dirs,
-                               int n_bins, float* d_power, hipStream_t stream)
+                               int n_bins, float* d_power, float* d_work, size_t work_floats, hipStream_t stream)
 {
     GemmArgs g{xre_mf, xim_mf, are, aim, d_power, nullptr, n_frames, n_dirs, n_mics, n_bins, 0, 1.0f};
-    return run_gemm<EPI_POWER>(g, stream);
+    // row tiles (32 frames each) per wave: at most 4 (its |C|^2 accumulators live in registers), balanced over the row groups
+    const int tiles = (n_frames + 31) / 32;
+    const int row_groups = (tiles + 3) / 4;
+    const int rt = (tiles + row_groups - 1) / row_groups;
+    const size_t plane = (size_t)n_frames * n_dirs;
+    switch (rt) {
+        case 1: return run_bins<EPI_POWER, 1>(g, row_groups, d_work, work_floats, plane, stream);
+        case 2: return run_bins<EPI_POWER, 2>(g, row_groups, d_work, work_floats, plane, stream);
+        case 3: return run_bins<EPI_POWER, 3>(g, row_groups, d_work, work_floats, plane, stream);
+        default: return run_bins<EPI_POWER, 4>(g, row_groups, d_work, work_floats, plane, stream);
+    }
 }
 
 hipError_t launch_fd_covariance(const float* xre_fm, const float* xim_fm, int n_frames, int n_mics, int n_bins, float* rre, float* rim, hipStream_t stream)
@@ -294,12 +498,12 @@ hipError_t launch_fd_cholesky_inverse(const float* rre, const float* rim, int n_
 }
 
 hipError_t launch_fd_mvdr_power(const float* lire_t, const float* liim_t, const float* are, const float* aim, int n_mics, int n_dirs, int n_bins,
-                                float* d_power, hipStream_t stream)
+                                float* d_power, float* d_work, size_t work_floats, hipStream_t stream)
 {
     // y = Linv a:  A = Linv ([K=col][I=row], i.e. the transposed planes), B = a ([K=mic][J=dir]);  P[d] = sum_k 1 / ||y||^2
     // the steering vector in the w^H x sense is v = conj(a) (the delay-and-sum output is sum_m a_m x_m = v^H x)
     GemmArgs g{lire_t, liim_t, are, aim, d_power, nullptr, n_mics, n_dirs, n_mics, n_bins, 1, 1.0f};
-    return run_gemm<EPI_MVDR>(g, stream);
+    return run_bins<EPI_MVDR, 1>(g, 1, d_work, work_floats, (size_t)n_dirs, stream);
 }
 
 }  // namespace bf
