@@ -1125,12 +1125,18 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
     }
 
     // Tile size: enough workgroups to fill the chip a few times over, but as many directions per staged block
-    // as possible.  A tile is a whole number of wave groups.
+    // as possible.  A tile is a whole number of wave groups -- except for small launches (a single frame through the
+    // host-pointer API), where latency matters: then every CU gets a tile, even if that leaves waves of a group idle.
     const int group = p.waves * p.dpw;
     const long long dirs = (long long)(L.dir_end - L.dir_begin);
     const long long target_wgs = (long long)n_cus * 4;
     long long td = (dirs * L.frames + target_wgs - 1) / target_wgs;
-    td = round_up((int)(td < group ? group : td > 512 ? 512 : td), group);
+    if (dirs * L.frames < (long long)n_cus * group) {
+        td = (dirs * L.frames + n_cus - 1) / n_cus;
+        td = round_up((int)(td < 1 ? 1 : td), p.dpw);
+    } else {
+        td = round_up((int)(td < group ? group : td > 512 ? 512 : td), group);
+    }
     p.tile_dirs = (int)td;
     p.n_tiles = round_up((int)((dirs + td - 1) / td), 8);
     *plan = p;

@@ -332,69 +332,87 @@ __global__ void __launch_bounds__(256) steering_kernel(const double* __restrict_
 }
 
 // Per bin: R += delta * tr(R)/M * I;  R = L L^H (Cholesky, lower);  Linv = L^-1;  stores Linv TRANSPOSED planes
-// [bin][col][row] (the A-operand layout of the MVDR GEMM).  One workgroup per bin, everything in LDS (M <= 128).
+// [bin][col][row] (the A-operand layout of the MVDR GEMM).  One workgroup per bin, everything in LDS (M <= 128), rows
+// padded to M + 1 floats so that column walks hit distinct banks.
+//   * factorisation: right-looking, ONE barrier per column -- the column is left unscaled while the trailing block is
+//     updated with a_ij conj(a_cj) / d_j, and all columns are scaled by 1 / sqrt(d_j) afterwards;
+//   * inverse: column c of L^-1 by forward substitution, 4 lanes per column splitting the dot product, written into the
+//     (free) upper triangle at the transposed position, which is exactly the output layout.
 __global__ void __launch_bounds__(256) cholesky_inverse_kernel(const float* __restrict__ rre, const float* __restrict__ rim, int M, float loading,
                                                                float* __restrict__ lire_t, float* __restrict__ liim_t, int* __restrict__ status)
 {
     extern __shared__ float sm[];
-    float* Lr = sm;                 // M*M
-    float* Li = sm + M * M;         // M*M
-    __shared__ float s_diag, s_trace;
+    const int LD = M + 1;
+    float* Lr = sm;                 // M * LD
+    float* Li = sm + M * LD;        // M * LD
+    __shared__ float s_trace;
+    __shared__ float rdiag[128];    // 1 / L[i][i]
     const int b = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
     const float* Rr = rre + (size_t)b * M * M;
     const float* Ri = rim + (size_t)b * M * M;
-    for (int i = t; i < M * M; i += nt) { Lr[i] = Rr[i]; Li[i] = Ri[i]; }
+    for (int i = t; i < M * M; i += nt) {
+        const int r = i / M, c = i - r * M;
+        Lr[r * LD + c] = Rr[i];
+        Li[r * LD + c] = Ri[i];
+    }
     __syncthreads();
     if (t == 0) {
         float tr = 0.0f;
-        for (int i = 0; i < M; ++i) tr += Lr[i * M + i];
+        for (int i = 0; i < M; ++i) tr += Lr[i * LD + i];
         s_trace = tr / (float)M;
     }
     __syncthreads();
-    if (t < M) { Lr[t * M + t] += loading * s_trace; Li[t * M + t] = 0.0f; }
-    __syncthreads();
-    // right-looking Cholesky on the lower triangle
+    if (t < M) { Lr[t * LD + t] += loading * s_trace; Li[t * LD + t] = 0.0f; }
+
+    const int ti = t >> 4, tc = t & 15;
     for (int j = 0; j < M; ++j) {
-        if (t == 0) {
-            const float d = Lr[j * M + j];
-            if (!(d > 0.0f)) status[b] = j + 1;
-            s_diag = sqrtf(fmaxf(d, 1e-30f));
-            Lr[j * M + j] = s_diag;
-        }
-        __syncthreads();
-        const float inv = 1.0f / s_diag;
-        for (int i = j + 1 + t; i < M; i += nt) { Lr[i * M + j] *= inv; Li[i * M + j] *= inv; }
-        __syncthreads();
-        // trailing update: A[i][c] -= L[i][j] * conj(L[c][j]),  j < c <= i
-        const int rem = M - j - 1;
-        for (int e = t; e < rem * rem; e += nt) {
-            const int i = j + 1 + e / rem, c = j + 1 + e % rem;
-            if (c <= i) {
-                const float ar = Lr[i * M + j], ai = Li[i * M + j], br = Lr[c * M + j], bi = Li[c * M + j];
-                Lr[i * M + c] -= ar * br + ai * bi;
-                Li[i * M + c] -= ai * br - ar * bi;
+        __syncthreads();                       // column j and d_j are final
+        const float d = Lr[j * LD + j];
+        if (t == 0 && !(d > 0.0f)) status[b] = j + 1;
+        const float invd = 1.0f / fmaxf(d, 1e-30f);
+        // trailing update: A[i][c] -= a_ij conj(a_cj) / d_j,  j < c <= i
+        for (int i = j + 1 + ti; i < M; i += 16) {
+            const float sr = Lr[i * LD + j] * invd, si = Li[i * LD + j] * invd;
+            for (int c = j + 1 + tc; c <= i; c += 16) {
+                const float br = Lr[c * LD + j], bi = Li[c * LD + j];
+                Lr[i * LD + c] -= sr * br + si * bi;
+                Li[i * LD + c] -= si * br - sr * bi;
             }
         }
-        __syncthreads();
     }
-    // invert the lower-triangular L column by column: thread c solves L x = e_c (forward substitution), x overwrites nothing in L
+    __syncthreads();
+    if (t < M) rdiag[t] = 1.0f / sqrtf(fmaxf(Lr[t * LD + t], 1e-30f));     // 1 / L[t][t]
+    __syncthreads();
+    for (int e = t; e < M * M; e += nt) {       // L[i][j] = a_ij / sqrt(d_j), strictly lower part
+        const int i = e / M, j = e - i * M;
+        if (j < i) { Lr[i * LD + j] *= rdiag[j]; Li[i * LD + j] *= rdiag[j]; }
+    }
+
+    // x = column c of L^-1:  x[c] = 1 / L[c][c];  x[i] = -(sum_{p=c}^{i-1} L[i][p] x[p]) / L[i][i].   x[i] (i > c) lives at [c][i].
+    const int q = t & 3;
+    for (int i = 1; i < M; ++i) {
+        __syncthreads();                        // the scaled L (first pass) / every x[p], p < i
+        for (int c = t >> 2; c < i; c += nt >> 2) {
+            float sr = 0.0f, si = 0.0f;
+            for (int p = c + q; p < i; p += 4) {
+                const float lr = Lr[i * LD + p], li = Li[i * LD + p];
+                const float xr = (p == c) ? rdiag[c] : Lr[c * LD + p];
+                const float xi = (p == c) ? 0.0f : Li[c * LD + p];
+                sr += lr * xr - li * xi;
+                si += lr * xi + li * xr;
+            }
+            sr += __shfl_xor(sr, 1, 64); si += __shfl_xor(si, 1, 64);
+            sr += __shfl_xor(sr, 2, 64); si += __shfl_xor(si, 2, 64);
+            if (q == 0) { Lr[c * LD + i] = -sr * rdiag[i]; Li[c * LD + i] = -si * rdiag[i]; }
+        }
+    }
+    __syncthreads();
     float* Or = lire_t + (size_t)b * M * M;
     float* Oi = liim_t + (size_t)b * M * M;
-    for (int c = t; c < M; c += nt) {
-        // x[i] = (delta_ic - sum_{p<i} L[i][p] x[p]) / L[i][i]; entries above the diagonal are zero
-        for (int i = 0; i < M; ++i) {
-            float xr = (i == c) ? 1.0f : 0.0f, xi = 0.0f;
-            if (i < c) { Or[(size_t)c * M + i] = 0.0f; Oi[(size_t)c * M + i] = 0.0f; continue; }
-            for (int p = c; p < i; ++p) {
-                const float lr = Lr[i * M + p], li = Li[i * M + p];
-                const float pr = Or[(size_t)c * M + p], pi = Oi[(size_t)c * M + p];   // x[p] (Linv[p][c]) stored at [c][p]
-                xr -= lr * pr - li * pi;
-                xi -= lr * pi + li * pr;
-            }
-            const float inv = 1.0f / Lr[i * M + i];
-            Or[(size_t)c * M + i] = xr * inv;   // Linv[i][c] at transposed position [c][i]
-            Oi[(size_t)c * M + i] = xi * inv;
-        }
+    for (int e = t; e < M * M; e += nt) {       // transposed planes: [c][i] = Linv[i][c]
+        const int c = e / M, i = e - c * M;
+        Or[e] = i < c ? 0.0f : (i == c ? rdiag[c] : Lr[c * LD + i]);
+        Oi[e] = i <= c ? 0.0f : Li[c * LD + i];
     }
 }
 
@@ -490,7 +508,7 @@ hipError_t launch_fd_covariance(const float* xre_fm, const float* xim_fm, int n_
 hipError_t launch_fd_cholesky_inverse(const float* rre, const float* rim, int n_mics, int n_bins, float loading, float* lire_t, float* liim_t,
                                       int* d_status, hipStream_t stream)
 {
-    const size_t lds = (size_t)2 * n_mics * n_mics * sizeof(float);
+    const size_t lds = (size_t)2 * n_mics * (n_mics + 1) * sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cholesky_inverse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(cholesky_inverse_kernel, dim3((unsigned)n_bins), dim3(256), lds, stream, rre, rim, n_mics, loading, lire_t, liim_t, d_status);
