@@ -39,8 +39,8 @@ struct DevBuf {
         if (n <= cap) return hipSuccess;
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
-        // 64 bytes of slack: the scalar-table kernels fetch 16 entries at a time and may run past the last row
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T) + 64);
+        // slack: the scalar-table kernels fetch 16 entries (or 4 mics x 8 taps) at a time and may run past the last row
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T) + 256);
         if (e == hipSuccess) cap = n;
         return e;
     }
@@ -278,7 +278,7 @@ bool plan_or_error(bf::DasLaunch& L, bf::DasPlan* plan)
 // Shifted-copies layout with scalar tables: make sure the table set carries a digest built for this plan.
 bool ensure_digest(TableSet& t, bf::DasLaunch& L, const bf::DasPlan& plan, hipStream_t stream)
 {
-    if (plan.layout != 2) return true;
+    if (plan.layout != 2 || L.algo == bf::ALGO_FIR_NAIVE || L.algo == bf::ALGO_FIR_VEC) return true;   // the plain FIRs have no whole-sample table
     const long long key = ((long long)plan.mic_chunk << 40) ^ ((long long)plan.row_stride << 20) ^ ((long long)plan.lead << 4) ^ L.algo;
     if (t.digest_key != key || !t.digest.p) {
         if (!HIP_OK(t.digest.reserve((size_t)t.entries))) return false;

@@ -659,7 +659,39 @@ struct Geo {
     static constexpr int kLead = NSEG == 1 ? 48 : 64;                // zero prefix of the fixed-stride variant
     static constexpr int kRs = NSEG * 256 + kLead;                   // its row stride
     static constexpr int kPark = NSEG * 256 + 4;                     // floats per parked row of squares
+    static constexpr int kFirTail = 8;                               // 8-tap FIR rows: the reference's zero padding after the block
+    static constexpr int kRsFir = kRs + kFirTail;
 };
+
+// One 8-tap FIR step of the hybrid beamformer on a quad (hybrid_convolve_and_sum.c:51-64): output j of the lane (sample
+// k = 4 lane + j) takes  o_j = fma(h_t, W[j + t], o_j), t = 0..7 in order, but only where k > p (the reference starts at
+// i = 0, i.e. k = p + 1).  The live lanes of output j are a wave-uniform suffix of the wave, so the four guards are four
+// EXEC masks set by the scalar unit -- no per-lane compare / select on the VALU.  One asm statement: the compiler must
+// not move anything between the EXEC writes.
+__device__ __forceinline__ void fir8_masked(float (&o)[4], const float (&W)[12], const float (&h)[8], unsigned long long m0, unsigned long long m1,
+                                            unsigned long long m2, unsigned long long m3)
+{
+    unsigned long long saved;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[m0]\n\t"
+        "v_fmac_f32 %[o0], %[h0], %[w0]\n\tv_fmac_f32 %[o0], %[h1], %[w1]\n\tv_fmac_f32 %[o0], %[h2], %[w2]\n\tv_fmac_f32 %[o0], %[h3], %[w3]\n\t"
+        "v_fmac_f32 %[o0], %[h4], %[w4]\n\tv_fmac_f32 %[o0], %[h5], %[w5]\n\tv_fmac_f32 %[o0], %[h6], %[w6]\n\tv_fmac_f32 %[o0], %[h7], %[w7]\n\t"
+        "s_mov_b64 exec, %[m1]\n\t"
+        "v_fmac_f32 %[o1], %[h0], %[w1]\n\tv_fmac_f32 %[o1], %[h1], %[w2]\n\tv_fmac_f32 %[o1], %[h2], %[w3]\n\tv_fmac_f32 %[o1], %[h3], %[w4]\n\t"
+        "v_fmac_f32 %[o1], %[h4], %[w5]\n\tv_fmac_f32 %[o1], %[h5], %[w6]\n\tv_fmac_f32 %[o1], %[h6], %[w7]\n\tv_fmac_f32 %[o1], %[h7], %[w8]\n\t"
+        "s_mov_b64 exec, %[m2]\n\t"
+        "v_fmac_f32 %[o2], %[h0], %[w2]\n\tv_fmac_f32 %[o2], %[h1], %[w3]\n\tv_fmac_f32 %[o2], %[h2], %[w4]\n\tv_fmac_f32 %[o2], %[h3], %[w5]\n\t"
+        "v_fmac_f32 %[o2], %[h4], %[w6]\n\tv_fmac_f32 %[o2], %[h5], %[w7]\n\tv_fmac_f32 %[o2], %[h6], %[w8]\n\tv_fmac_f32 %[o2], %[h7], %[w9]\n\t"
+        "s_mov_b64 exec, %[m3]\n\t"
+        "v_fmac_f32 %[o3], %[h0], %[w3]\n\tv_fmac_f32 %[o3], %[h1], %[w4]\n\tv_fmac_f32 %[o3], %[h2], %[w5]\n\tv_fmac_f32 %[o3], %[h3], %[w6]\n\t"
+        "v_fmac_f32 %[o3], %[h4], %[w7]\n\tv_fmac_f32 %[o3], %[h5], %[w8]\n\tv_fmac_f32 %[o3], %[h6], %[w9]\n\tv_fmac_f32 %[o3], %[h7], %[w10]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [o0] "+v"(o[0]), [o1] "+v"(o[1]), [o2] "+v"(o[2]), [o3] "+v"(o[3]), [sv] "=&s"(saved)
+        : [h0] "v"(h[0]), [h1] "v"(h[1]), [h2] "v"(h[2]), [h3] "v"(h[3]), [h4] "v"(h[4]), [h5] "v"(h[5]), [h6] "v"(h[6]), [h7] "v"(h[7]),
+          [w0] "v"(W[0]), [w1] "v"(W[1]), [w2] "v"(W[2]), [w3] "v"(W[3]), [w4] "v"(W[4]), [w5] "v"(W[5]), [w6] "v"(W[6]), [w7] "v"(W[7]),
+          [w8] "v"(W[8]), [w9] "v"(W[9]), [w10] "v"(W[10]), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3));
+}
 
 // What one thread holds of a staged (mic, segment) pair between its global load and its LDS write.
 struct Staged {
@@ -693,8 +725,9 @@ __device__ __forceinline__ void write_copies(float* row0, int rs, int col, int l
 template <int ALGO, int NSEG, int RS>
 __global__ void __launch_bounds__(1024, 4) das_copies_kernel(BF_TABLE_PARAMS, KArgs a)
 {
-    static_assert(ALGO == ALGO_PAD || ALGO == ALGO_LERP, "shifted-copies layout: pad and lerp");
-    static_assert(RS == 0 || RS == Geo<NSEG>::kRs, "fixed row stride");
+    constexpr bool FIR = ALGO == ALGO_HYBRID || ALGO == ALGO_FIR_NAIVE || ALGO == ALGO_FIR_VEC;   // 8 taps, N <= 256
+    static_assert(!FIR || NSEG == 1, "the FIR flavours use the one-segment geometry");
+    static_assert(RS == 0 || RS == (FIR ? Geo<NSEG>::kRsFir : Geo<NSEG>::kRs), "fixed row stride");
     constexpr int A = (ALGO == ALGO_LERP) ? 2 : 1;   // arrays per mic: s (and D)
     constexpr int DW = Geo<NSEG>::kDw, U = Geo<NSEG>::kBatch, kGroup = Geo<NSEG>::kGroup, kPark = Geo<NSEG>::kPark;
     constexpr int SP = (NSEG > 1 && ALGO == ALGO_PAD) ? 2 : 1;   // (mic, segment) pairs a wave stages per chunk
@@ -708,11 +741,12 @@ __global__ void __launch_bounds__(1024, 4) das_copies_kernel(BF_TABLE_PARAMS, KA
     if (tile_begin >= a.dir_end) return;
     const int tile_end = min(tile_begin + a.tile_dirs, a.dir_end);
 
-    const int rs = RS > 0 ? RS : a.row_stride, lead = RS > 0 ? Geo<NSEG>::kLead : a.lead;
+    const int rs = RS > 0 ? RS : a.row_stride, lead = RS > 0 ? Geo<NSEG>::kLead : a.lead;   // (kRsFir has the same lead, plus the tail)
     const int mc = a.mic_chunk, M = a.n_mics, N = a.n_samples;
     const float* __restrict__ frame_sig = signals + (size_t)frame * a.m_total * N;
     float* __restrict__ img = images + (size_t)frame * a.image_stride;
-    const int32_t* __restrict__ dig = reinterpret_cast<const int32_t*>(taps);
+    // the digest rides in a pointer slot the algorithm does not use: taps (pad, lerp) or frac (hybrid)
+    const int32_t* __restrict__ dig = reinterpret_cast<const int32_t*>(FIR ? frac : taps);
     const int slot_floats = A * 4 * rs;   // floats per staged mic
 
     // Rows of `signals` this wave stages: pair index pr = wave + 16 i  <->  chunk mic pr / NSEG, segment pr % NSEG.
@@ -768,6 +802,21 @@ __global__ void __launch_bounds__(1024, 4) das_copies_kernel(BF_TABLE_PARAMS, KA
                 if (lane == 63) nx = en;
             }
             write_copies(row0, rs, col, lane, v, py, pz, pw);
+            if constexpr (FIR) {
+                // the zero padding after the block (convolve_and_sum.c:199-203): quad 64 of copy c still holds the last c
+                // samples, quad 65 is zero
+                if (lane == kWave - 1) {
+                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    float4* t0 = reinterpret_cast<float4*>(row0 + col + 256);
+                    t0[0] = z; t0[1] = z;
+                    float4* t1 = reinterpret_cast<float4*>(row0 + rs + col + 256);
+                    t1[0] = make_float4(v.w, 0.f, 0.f, 0.f); t1[1] = z;
+                    float4* t2 = reinterpret_cast<float4*>(row0 + 2 * rs + col + 256);
+                    t2[0] = make_float4(v.z, v.w, 0.f, 0.f); t2[1] = z;
+                    float4* t3 = reinterpret_cast<float4*>(row0 + 3 * rs + col + 256);
+                    t3[0] = make_float4(v.y, v.z, v.w, 0.f); t3[1] = z;
+                }
+            }
             if constexpr (ALGO == ALGO_LERP) {
                 // D[i] = s[i+1] - s[i], the reference's own subtraction (lerp_and_sum.c:54); D[-1] stays 0 (prefix)
                 const float4 dq = make_float4(v.y - v.x, v.z - v.y, v.w - v.z, nx - v.w);
@@ -811,6 +860,96 @@ __global__ void __launch_bounds__(1024, 4) das_copies_kernel(BF_TABLE_PARAMS, KA
                 if (nch == a.n_chunks) { nch = 0; ng0 = g0 + kGroup; }
                 if (ng0 < tile_end) fetch(nch, min(mc, M - nch * mc), staged);
             }
+            // 8-tap FIR flavours: per (direction, mic) the lane's 4 outputs need 11 consecutive samples = 3 aligned quads
+            // of one copy (immediate offsets 0 / 16 / 32).  The 8 taps of a (direction, mic) are fetched with two broadcast
+            // vector loads (every lane the same address): scalar loads would share the LDS wait counter and stall every
+            // step, vector loads have their own (vmcnt) and are prefetched four mics ahead.  LDS offsets and delays of the
+            // 16 mics come by s_load once per direction.
+            auto fir_directions = [&](auto mcc_c) {
+                constexpr int MCC = decltype(mcc_c)::value;     // > 0: compile-time mic count, software-pipelined; 0: any count
+                int vz = 0;
+                asm volatile("" : "+v"(vz));                    // an opaque zero: keeps the tap loads on the vector memory path
+#pragma unroll
+                for (int j = 0; j < DW; ++j) {
+                    const int d = g0 + wave * DW + j;           // wave-uniform
+                    if (d >= tile_end) continue;
+                    const size_t idx = (size_t)d * M + m0;
+                    const float4* __restrict__ tp = reinterpret_cast<const float4*>(taps + idx * 8) + vz;
+                    int e[16], pw[16];
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) {
+                        if constexpr (ALGO == ALGO_HYBRID) {
+                            e[m] = dig[idx + m];
+                            pw[m] = whole[idx + m];
+                        } else {
+                            // convolve_and_sum.c:197-211: no whole-sample shift, window starts T/2 = 4 samples back: copy 0
+                            e[m] = ((m * 4) * rs + lead - 4) * 4;
+                            pw[m] = 0;
+                        }
+                    }
+                    float o[4] = {acc[j][0][0].x, acc[j][0][0].y, acc[j][0][1].x, acc[j][0][1].y};
+                    auto consume = [&](const float4 (&hq)[2], const float4 (&q)[3], int pp) {
+                        const float h[8] = {hq[0].x, hq[0].y, hq[0].z, hq[0].w, hq[1].x, hq[1].y, hq[1].z, hq[1].w};
+                        const float W[12] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w};
+                        if constexpr (ALGO == ALGO_HYBRID) {
+                            // output j (sample 4 lane + j) is live for 4 lane + j > p: the first n_j = (p + 4 - j) >> 2 lanes are not
+                            auto mask = [](int n) -> unsigned long long { return n >= 64 ? 0ull : (~0ull << n); };
+                            fir8_masked(o, W, h, mask((pp + 4) >> 2), mask((pp + 3) >> 2), mask((pp + 2) >> 2), mask((pp + 1) >> 2));
+                        } else if constexpr (ALGO == ALGO_FIR_NAIVE) {
+                            // convolve_and_sum.c:197-211  out[i] += h[t] * padded[i + t], t in order (fma chain into out)
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                                for (int t = 0; t < 8; ++t) o[jj] = __fmaf_rn(h[t], W[jj + t], o[jj]);
+                        } else {
+                            // convolve_and_sum.c:158-192 + sum8 :132-153 with one AVX block: eight plain products, fixed tree, out +=
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) {
+                                const float* x = W + jj;
+                                const float q0 = x[0] * h[0] + x[4] * h[4], q1 = x[1] * h[1] + x[5] * h[5];
+                                const float q2 = x[2] * h[2] + x[6] * h[6], q3 = x[3] * h[3] + x[7] * h[7];
+                                o[jj] += (q0 + q2) + (q1 + q3);
+                            }
+                        }
+                    };
+                    if constexpr (MCC > 0) {
+                        constexpr int RH = 4, RQ = 2;           // mics of taps / of sample quads in flight
+                        float4 H[RH][2], Q[RQ][3];
+                        auto load_taps = [&](int i, int slot) { H[slot][0] = tp[2 * i]; H[slot][1] = tp[2 * i + 1]; };
+                        auto load_quads = [&](int i, int slot) {
+                            const char* sp = lbase + e[i];
+                            Q[slot][0] = *reinterpret_cast<const float4*>(sp);
+                            Q[slot][1] = *reinterpret_cast<const float4*>(sp + 16);
+                            Q[slot][2] = *reinterpret_cast<const float4*>(sp + 32);
+                        };
+#pragma unroll
+                        for (int i = 0; i < RH && i < MCC; ++i) load_taps(i, i);
+#pragma unroll
+                        for (int i = 0; i < RQ && i < MCC; ++i) load_quads(i, i);
+#pragma unroll
+                        for (int i = 0; i < MCC; ++i) {
+                            consume(H[i % RH], Q[i % RQ], pw[i]);
+                            if (i + RH < MCC) load_taps(i + RH, i % RH);
+                            if (i + RQ < MCC) load_quads(i + RQ, i % RQ);
+                            asm volatile("" ::: "memory");      // keeps the prefetch distance: later loads stay below this point
+                        }
+                    } else {
+                        for (int i = 0; i < mcc; ++i) {
+                            // (runtime index into e / pw: pick through a uniform select chain the compiler keeps in SGPRs)
+                            int ei = e[0], pi = pw[0];
+#pragma unroll
+                            for (int m = 1; m < 16; ++m) { ei = (i == m) ? e[m] : ei; pi = (i == m) ? pw[m] : pi; }
+                            float4 hq[2] = {tp[2 * i], tp[2 * i + 1]};
+                            const char* sp = lbase + ei;
+                            float4 q[3] = {*reinterpret_cast<const float4*>(sp), *reinterpret_cast<const float4*>(sp + 16),
+                                           *reinterpret_cast<const float4*>(sp + 32)};
+                            consume(hq, q, pi);
+                        }
+                    }
+                    acc[j][0][0] = f32x2{o[0], o[1]};
+                    acc[j][0][1] = f32x2{o[2], o[3]};
+                }
+            };
             // One direction at a time, its staged mics in order, U mics x NSEG segments of reads in flight.
             auto directions = [&](auto mcc_c) {
                 // MCC > 0: the chunk's mic count at compile time (a whole number of batches): straight-line code, no
@@ -889,7 +1028,11 @@ __global__ void __launch_bounds__(1024, 4) das_copies_kernel(BF_TABLE_PARAMS, KA
             };
             // N <= 256: the chunk sizes the planner picks get straight-line code.  With more segments the 64 accumulator
             // registers leave no room for the deeper read pipelining that buys (it spills), so only the branchy form.
-            if constexpr (NSEG == 1) {
+            if constexpr (FIR) {
+                if (mcc == 16) fir_directions(std::integral_constant<int, 16>{});
+                else if (mcc == 8) fir_directions(std::integral_constant<int, 8>{});
+                else fir_directions(std::integral_constant<int, 0>{});
+            } else if constexpr (NSEG == 1) {
                 if (mcc == 16) directions(std::integral_constant<int, 16>{});
                 else if (mcc == 8) directions(std::integral_constant<int, 8>{});
                 else directions(std::integral_constant<int, 0>{});
@@ -964,18 +1107,22 @@ hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, in
         hipLaunchKernelGGL(kernel, grid, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole, L.tab.frac, L.tab.taps, a);
         return hipGetLastError();
     };
-    if constexpr (NC >= 4 && (ALGO == ALGO_PAD || ALGO == ALGO_LERP)) {
+    constexpr bool kFir = ALGO == ALGO_HYBRID || ALGO == ALGO_FIR_NAIVE || ALGO == ALGO_FIR_VEC;
+    if constexpr ((NC >= 4 && !kFir) || (NC == 4 && kFir)) {
         if (plan.layout == 2) {
-            if (L.tab.digest == nullptr) return hipErrorInvalidValue;   // launch_digest first
+            constexpr bool kNeedsDigest = ALGO != ALGO_FIR_NAIVE && ALGO != ALGO_FIR_VEC;
+            if (kNeedsDigest && L.tab.digest == nullptr) return hipErrorInvalidValue;   // launch_digest first
+            if (kFir && L.n_taps != 8) return hipErrorInvalidValue;
             constexpr int NSEG = NC / 4;
             using G = copies::Geo<NSEG>;
-            auto kernel = plan.row_stride == G::kRs && plan.lead == G::kLead ? copies::das_copies_kernel<ALGO, NSEG, G::kRs>
-                                                                             : copies::das_copies_kernel<ALGO, NSEG, 0>;
+            constexpr int kRs = kFir ? G::kRsFir : G::kRs;
+            auto kernel = plan.row_stride == kRs && plan.lead == G::kLead ? copies::das_copies_kernel<ALGO, NSEG, kRs> : copies::das_copies_kernel<ALGO, NSEG, 0>;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
             if (e != hipSuccess) return e;
-            // the digest rides in the (unused) taps slot
-            hipLaunchKernelGGL(kernel, grid, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole, L.tab.frac,
-                               reinterpret_cast<const float*>(L.tab.digest), a);
+            // the digest rides in a pointer slot the algorithm does not use: taps (pad, lerp) or frac (hybrid)
+            const float* dig = reinterpret_cast<const float*>(L.tab.digest);
+            hipLaunchKernelGGL(kernel, grid, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole, kFir ? dig : L.tab.frac,
+                               kFir ? L.tab.taps : dig, a);
             return hipGetLastError();
         }
     }
@@ -1088,18 +1235,22 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
         p.mic_chunk = mc; p.n_chunks = (L.n_mics + mc - 1) / mc;
         p.dpw = p.n_chunks > 1 ? 4 : 1;
     }
-    // Layout for pad / lerp at 128 < N <= 1024: 2 = shifted copies (default), 0 = strided; N <= 256 only: 1 = quad + DPP.
-    const bool copies_ok = p.nc >= 4 && (L.algo == ALGO_PAD || L.algo == ALGO_LERP);
+    // Layout for pad / lerp at 128 < N <= 1024 and for the 8-tap FIR flavours at 128 < N <= 256: 2 = shifted copies
+    // (default), 0 = strided; pad / lerp at N <= 256 only: 1 = quad + DPP.
+    const bool plain = L.algo == ALGO_PAD || L.algo == ALGO_LERP;
+    const bool copies_ok = plain ? p.nc >= 4 : (p.nc == 4 && L.n_taps == 8);
     p.layout = copies_ok ? (L.force_layout >= 0 ? L.force_layout : 2) : 0;
-    if (p.layout == 1 && p.nc != 4) p.layout = 0;
+    if (p.layout == 1 && !(plain && p.nc == 4)) p.layout = 0;
     p.quad = p.layout == 1 ? 1 : 0;
     if (p.layout == 2) {
         const int nseg = p.nc / 4, arrays = (L.algo == ALGO_LERP) ? 2 : 1;
         const int fixed_lead = nseg == 1 ? copies::Geo<1>::kLead : copies::Geo<4>::kLead;   // Geo<2> == Geo<4> here
         const int dw = nseg == 4 ? copies::Geo<4>::kDw : copies::Geo<1>::kDw;               // Geo<2> == Geo<1> here
-        p.lead = round_up(L.tab.max_whole + 2, 4);       // lerp folds its extra sample into the delay (p + 1)
+        // zero prefix: the furthest look-back is the delay (+1 for lerp, +1 + T/2 for hybrid, T/2 for the plain FIRs)
+        const int back = L.algo == ALGO_HYBRID ? L.tab.max_whole + 1 + L.n_taps / 2 : fir ? L.n_taps / 2 : L.tab.max_whole + 1;
+        p.lead = round_up(back + 1, 4);
         if (p.lead <= fixed_lead && !(L.debug & 2)) p.lead = fixed_lead;   // compile-time row stride
-        p.row_stride = p.lead + nseg * 256;
+        p.row_stride = p.lead + nseg * 256 + (fir ? copies::Geo<1>::kFirTail : 0);
         const size_t slot_bytes = (size_t)arrays * 4 * p.row_stride * sizeof(float);
         // a chunk: as many mics as fit beside nothing else in 156 KiB, at most 16 (one s_load of table entries) and at
         // most what the 16 waves stage in one go (one (mic, segment) pair each; two for pad with several segments)
@@ -1146,7 +1297,9 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
 
 hipError_t launch_digest(const int32_t* d_whole, int32_t* d_digest, long long entries, int n_mics, const DasPlan& plan, int algo, hipStream_t stream)
 {
-    const int arrays = (algo == ALGO_LERP) ? 2 : 1, bias = (algo == ALGO_LERP) ? 1 : 0;
+    // what the kernel looks back by beyond the whole-sample delay: lerp reads s[k - p - 1], hybrid starts its window at
+    // s[k - p - 1 - T/2] (T = 8)
+    const int arrays = (algo == ALGO_LERP) ? 2 : 1, bias = (algo == ALGO_LERP) ? 1 : (algo == ALGO_HYBRID) ? 5 : 0;
     hipLaunchKernelGGL(digest_kernel, dim3(1024), dim3(256), 0, stream, d_whole, d_digest, entries, n_mics, plan.mic_chunk, arrays, plan.row_stride,
                        plan.lead, bias);
     return hipGetLastError();
