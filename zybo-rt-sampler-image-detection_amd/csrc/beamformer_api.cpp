@@ -279,10 +279,12 @@ bool plan_or_error(bf::DasLaunch& L, bf::DasPlan* plan)
 bool ensure_digest(TableSet& t, bf::DasLaunch& L, const bf::DasPlan& plan, hipStream_t stream)
 {
     if (plan.layout != 2 || L.algo == bf::ALGO_FIR_NAIVE || L.algo == bf::ALGO_FIR_VEC) return true;   // the plain FIRs have no whole-sample table
-    const long long key = ((long long)plan.mic_chunk << 40) ^ ((long long)plan.row_stride << 20) ^ ((long long)plan.lead << 4) ^ L.algo;
+    // everything the digest depends on: the plan's geometry, the algorithm and (grouped layouts) the direction range
+    const long long key = ((long long)plan.mic_chunk << 40) ^ ((long long)plan.row_stride << 20) ^ ((long long)plan.lead << 4) ^ L.algo ^
+                          ((long long)plan.dpw << 52) ^ ((long long)L.dir_begin * 1000003LL) ^ ((long long)L.dir_end * 7919LL << 8);
     if (t.digest_key != key || !t.digest.p) {
-        if (!HIP_OK(t.digest.reserve((size_t)t.entries))) return false;
-        if (!HIP_OK(bf::launch_digest(t.whole.p, t.digest.p, t.entries, L.n_mics, plan, L.algo, stream))) return false;
+        if (!HIP_OK(t.digest.reserve(bf::digest_elements(L, plan)))) return false;
+        if (!HIP_OK(bf::launch_digest(L, plan, t.digest.p, stream))) return false;
         t.digest_key = key;
     }
     L.tab.digest = t.digest.p;

@@ -22,7 +22,8 @@ struct DeviceTables {
     const float* frac = nullptr;     // [D][M]      h = 1 - frac              (lerp)
     const float* taps = nullptr;     // [D][M][T]   FIR taps                  (hybrid, fir)
     int max_whole = 0;               // max over the table, clamped to N (sizes the zero prefix in LDS)
-    const int32_t* digest = nullptr; // [D][M] LDS byte offsets for the shifted-copies layout (launch_digest), or null
+    const int32_t* digest = nullptr; // LDS byte offsets for the shifted-copies layout (launch_digest): grouped by the wave's directions for pad / lerp
+                                     // (+ the lerp weights in the same order), [D][M] for hybrid; null when not built
 };
 
 // Geometry of one launch.  Directions [dir_begin, dir_end) of every frame in [0, frames).
@@ -67,7 +68,8 @@ struct DasPlan {
 int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why);
 
 // Build DeviceTables::digest for the layout `plan` describes (shifted-copies layout only).
-hipError_t launch_digest(const int32_t* d_whole, int32_t* d_digest, long long entries, int n_mics, const DasPlan& plan, int algo, hipStream_t stream);
+size_t digest_elements(const DasLaunch& L, const DasPlan& plan);   // 4-byte elements the digest of this launch needs (0: none)
+hipError_t launch_digest(const DasLaunch& L, const DasPlan& plan, int32_t* d_digest, hipStream_t stream);
 
 // Enqueue on `stream`; no host synchronisation, no allocation (graph-capturable).
 hipError_t launch_das(const DasLaunch& L, const DasPlan& plan, hipStream_t stream);

@@ -39,6 +39,7 @@ struct KArgs {
     int n_is_pow2;
     float inv_n;
     int debug;   // profiling only (BF_DEBUG): bit 0 = skip the ordered power sum (wrong images)
+    long long digest_h_off;   // shifted-copies pad / lerp: where the grouped lerp weights start in the digest buffer (floats)
 };
 
 // The read-only tables are separate `const __restrict__` kernel parameters on purpose: only then can the
@@ -634,6 +635,41 @@ __global__ void __launch_bounds__(256) digest_kernel(const int32_t* __restrict__
     }
 }
 
+// Grouped digest for pad / lerp: directions are taken in groups of `gdirs` (= the directions one wave carries) counted
+// from dir_begin, and the group's entries of one mic sit together: entry ((g * M + m) * gdirs + j) = direction
+// dir_begin + g * gdirs + j, mic m, so one s_load_dwordx8 brings the 8 directions' offsets of a mic.  The lerp weights
+// follow in the same buffer (float, same order) at `h_off`.  Directions past dir_end repeat the last one (their results
+// are never stored).
+__global__ void __launch_bounds__(256) digest_grouped_kernel(const int32_t* __restrict__ whole, const float* __restrict__ frac, int32_t* __restrict__ digest,
+                                                             long long entries, long long h_off, int n_mics, int gdirs, int dir_begin, int dir_end,
+                                                             int mic_chunk, int arrays, int row_stride, int lead, int bias)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < entries; i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i % gdirs);
+        const long long gm = i / gdirs;
+        const int mic = (int)(gm % n_mics);
+        const long long g = gm / n_mics;
+        long long d = dir_begin + g * gdirs + j;
+        if (d > dir_end - 1) d = dir_end - 1;
+        const int m = mic % mic_chunk;
+        const int pd = whole[d * n_mics + mic] + bias;
+        int entry = ((m * arrays * 4 + (pd & 3)) * row_stride + lead - (pd & ~3)) * 4;
+        if (j == 0) {
+            // offsets are multiples of 16: bit 0 of a group's first entry says "every direction of the group reads the same
+            // quads of this mic" (one read, no per-direction test in the kernel)
+            bool same = true;
+            for (int jj = 1; jj < gdirs; ++jj) {
+                long long dj = dir_begin + g * gdirs + jj;
+                if (dj > dir_end - 1) dj = dir_end - 1;
+                same = same && whole[dj * n_mics + mic] == whole[d * n_mics + mic];
+            }
+            entry |= same ? 1 : 0;
+        }
+        digest[i] = entry;
+        if (frac != nullptr) reinterpret_cast<float*>(digest)[h_off + i] = frac[d * n_mics + mic];
+    }
+}
+
 namespace copies {
 
 constexpr int kWaves = 16;       // waves per workgroup
@@ -713,6 +749,140 @@ __device__ __forceinline__ void write_copies(float* row0, int rs, int col, int l
     *q3 = make_float4(py, pz, pw, v.x);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// The quad (two register pairs) of one 256-sample segment of a staged mic row, and of its difference row for lerp.
+struct Quad { f32x2 lo, hi; };
+
+// (Re)load the NSEG quads of a mic for LDS byte offset `e` -- unless `e` equals the offset they were loaded for (`ep`):
+// a scalar compare and branch, no vector work and no wait when the quads are still valid; a reload waits for its reads,
+// so the quads are usable afterwards.  One asm statement: the compiler sees an opaque in-place update of the registers and
+// cannot hoist, duplicate or speculate the reads.
+#define BF_RD(sg, off, off8)                                                   \
+    "ds_read_b64 %[s" #sg "l], %[ad] offset:" #off "\n\t"                      \
+    "ds_read_b64 %[s" #sg "h], %[ad] offset:" #off8 "\n\t"
+#define BF_RDD(sg, off, off8)                                                  \
+    "ds_read_b64 %[d" #sg "l], %[ad2] offset:" #off "\n\t"                     \
+    "ds_read_b64 %[d" #sg "h], %[ad2] offset:" #off8 "\n\t"
+// The reload path lives out of line (subsection 1 of the text section): the common case -- offset unchanged -- is a
+// compare and a NOT-taken branch, which costs the wave nothing; a taken branch per step did (instruction refetch).
+#define BF_RELOAD_HEAD "s_cmp_lg_u32 %[e], %[ep]\n\ts_cbranch_scc1 .Lreload_%=\n.Lback_%=:\n\t.subsection 1\n.Lreload_%=:\n\t"
+#define BF_RELOAD_TAIL "s_waitcnt lgkmcnt(0)\n\ts_branch .Lback_%=\n\t.subsection 0"
+#define BF_S_OPS(sg) [s##sg##l] "+v"(S[sg].lo), [s##sg##h] "+v"(S[sg].hi)
+#define BF_D_OPS(sg) [d##sg##l] "+v"(D[sg].lo), [d##sg##h] "+v"(D[sg].hi)
+
+template <int NSEG, bool LERP>
+__device__ __forceinline__ void reload_quads(Quad (&S)[NSEG], Quad (&D)[NSEG], int e, int ep, int lbase, int d_off)
+{
+    int ad, ad2;
+    if constexpr (NSEG == 1 && !LERP) {
+        asm volatile(BF_RELOAD_HEAD "v_add_u32 %[ad], %[e], %[lb]\n\t" BF_RD(0, 0, 8) BF_RELOAD_TAIL
+                     : BF_S_OPS(0), [ad] "=&v"(ad) : [e] "s"(e), [ep] "s"(ep), [lb] "v"(lbase) : "scc");
+    } else if constexpr (NSEG == 1 && LERP) {
+        asm volatile(BF_RELOAD_HEAD "v_add_u32 %[ad], %[e], %[lb]\n\tv_add_u32 %[ad2], %[ad], %[doff]\n\t" BF_RD(0, 0, 8)
+                         BF_RDD(0, 0, 8) BF_RELOAD_TAIL
+                     : BF_S_OPS(0), BF_D_OPS(0), [ad] "=&v"(ad), [ad2] "=&v"(ad2) : [e] "s"(e), [ep] "s"(ep), [lb] "v"(lbase), [doff] "s"(d_off) : "scc");
+    } else if constexpr (NSEG == 2 && !LERP) {
+        asm volatile(BF_RELOAD_HEAD "v_add_u32 %[ad], %[e], %[lb]\n\t" BF_RD(0, 0, 8) BF_RD(1, 1024, 1032)
+                     BF_RELOAD_TAIL
+                     : BF_S_OPS(0), BF_S_OPS(1), [ad] "=&v"(ad) : [e] "s"(e), [ep] "s"(ep), [lb] "v"(lbase) : "scc");
+    } else if constexpr (NSEG == 2 && LERP) {
+        asm volatile(BF_RELOAD_HEAD "v_add_u32 %[ad], %[e], %[lb]\n\tv_add_u32 %[ad2], %[ad], %[doff]\n\t" BF_RD(0, 0, 8)
+                         BF_RDD(0, 0, 8) BF_RD(1, 1024, 1032) BF_RDD(1, 1024, 1032) BF_RELOAD_TAIL
+                     : BF_S_OPS(0), BF_D_OPS(0), BF_S_OPS(1), BF_D_OPS(1), [ad] "=&v"(ad), [ad2] "=&v"(ad2)
+                     : [e] "s"(e), [ep] "s"(ep), [lb] "v"(lbase), [doff] "s"(d_off) : "scc");
+    } else if constexpr (NSEG == 4 && !LERP) {
+        asm volatile(BF_RELOAD_HEAD "v_add_u32 %[ad], %[e], %[lb]\n\t" BF_RD(0, 0, 8) BF_RD(1, 1024, 1032) BF_RD(2, 2048, 2056)
+                         BF_RD(3, 3072, 3080) BF_RELOAD_TAIL
+                     : BF_S_OPS(0), BF_S_OPS(1), BF_S_OPS(2), BF_S_OPS(3), [ad] "=&v"(ad) : [e] "s"(e), [ep] "s"(ep), [lb] "v"(lbase) : "scc");
+    } else {
+        static_assert(NSEG == 4 && LERP, "segments: 1, 2 or 4");
+        asm volatile(BF_RELOAD_HEAD "v_add_u32 %[ad], %[e], %[lb]\n\tv_add_u32 %[ad2], %[ad], %[doff]\n\t" BF_RD(0, 0, 8)
+                         BF_RDD(0, 0, 8) BF_RD(1, 1024, 1032) BF_RDD(1, 1024, 1032) BF_RD(2, 2048, 2056) BF_RDD(2, 2048, 2056) BF_RD(3, 3072, 3080) BF_RDD(3, 3072, 3080)
+                     BF_RELOAD_TAIL
+                     : BF_S_OPS(0), BF_D_OPS(0), BF_S_OPS(1), BF_D_OPS(1), BF_S_OPS(2), BF_D_OPS(2), BF_S_OPS(3), BF_D_OPS(3), [ad] "=&v"(ad), [ad2] "=&v"(ad2)
+                     : [e] "s"(e), [ep] "s"(ep), [lb] "v"(lbase), [doff] "s"(d_off) : "scc");
+    }
+}
+
+// Request the NSEG quads of a mic for LDS byte offset `e` WITHOUT waiting: the caller consumes them one mic later, after
+// an "s_waitcnt lgkmcnt(0)" of its own.  (The compiler does not know these reads are in flight: the registers are only
+// touched again by asm statements that follow that wait.)
+template <int NSEG, bool LERP>
+__device__ __forceinline__ void issue_quads(Quad (&S)[NSEG], Quad (&D)[NSEG], int e, int lbase, int d_off)
+{
+    int ad, ad2;
+    if constexpr (NSEG == 1 && !LERP) {
+        asm volatile("v_add_u32 %[ad], %[e], %[lb]\n\t" BF_RD(0, 0, 8) : BF_S_OPS(0), [ad] "=&v"(ad) : [e] "s"(e), [lb] "v"(lbase));
+    } else if constexpr (NSEG == 1 && LERP) {
+        asm volatile("v_add_u32 %[ad], %[e], %[lb]\n\tv_add_u32 %[ad2], %[ad], %[doff]\n\t" BF_RD(0, 0, 8) BF_RDD(0, 0, 8)
+                     : BF_S_OPS(0), BF_D_OPS(0), [ad] "=&v"(ad), [ad2] "=&v"(ad2) : [e] "s"(e), [lb] "v"(lbase), [doff] "s"(d_off));
+    } else if constexpr (NSEG == 2 && !LERP) {
+        asm volatile("v_add_u32 %[ad], %[e], %[lb]\n\t" BF_RD(0, 0, 8) BF_RD(1, 1024, 1032)
+                     : BF_S_OPS(0), BF_S_OPS(1), [ad] "=&v"(ad) : [e] "s"(e), [lb] "v"(lbase));
+    } else if constexpr (NSEG == 2 && LERP) {
+        asm volatile("v_add_u32 %[ad], %[e], %[lb]\n\tv_add_u32 %[ad2], %[ad], %[doff]\n\t" BF_RD(0, 0, 8) BF_RDD(0, 0, 8) BF_RD(1, 1024, 1032)
+                         BF_RDD(1, 1024, 1032)
+                     : BF_S_OPS(0), BF_D_OPS(0), BF_S_OPS(1), BF_D_OPS(1), [ad] "=&v"(ad), [ad2] "=&v"(ad2) : [e] "s"(e), [lb] "v"(lbase), [doff] "s"(d_off));
+    } else if constexpr (NSEG == 4 && !LERP) {
+        asm volatile("v_add_u32 %[ad], %[e], %[lb]\n\t" BF_RD(0, 0, 8) BF_RD(1, 1024, 1032) BF_RD(2, 2048, 2056) BF_RD(3, 3072, 3080)
+                     : BF_S_OPS(0), BF_S_OPS(1), BF_S_OPS(2), BF_S_OPS(3), [ad] "=&v"(ad) : [e] "s"(e), [lb] "v"(lbase));
+    } else {
+        asm volatile("v_add_u32 %[ad], %[e], %[lb]\n\tv_add_u32 %[ad2], %[ad], %[doff]\n\t" BF_RD(0, 0, 8) BF_RDD(0, 0, 8) BF_RD(1, 1024, 1032)
+                         BF_RDD(1, 1024, 1032) BF_RD(2, 2048, 2056) BF_RDD(2, 2048, 2056) BF_RD(3, 3072, 3080) BF_RDD(3, 3072, 3080)
+                     : BF_S_OPS(0), BF_D_OPS(0), BF_S_OPS(1), BF_D_OPS(1), BF_S_OPS(2), BF_D_OPS(2), BF_S_OPS(3), BF_D_OPS(3), [ad] "=&v"(ad), [ad2] "=&v"(ad2)
+                     : [e] "s"(e), [lb] "v"(lbase), [doff] "s"(d_off));
+    }
+}
+// "the quads requested by issue_quads have arrived" (also drains outstanding scalar loads: same counter)
+template <int NSEG>
+__device__ __forceinline__ void await_quads(Quad (&S)[NSEG], Quad (&D)[NSEG])
+{
+    if constexpr (NSEG == 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : BF_S_OPS(0), BF_D_OPS(0));
+    } else if constexpr (NSEG == 2) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : BF_S_OPS(0), BF_D_OPS(0), BF_S_OPS(1), BF_D_OPS(1));
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : BF_S_OPS(0), BF_D_OPS(0), BF_S_OPS(1), BF_D_OPS(1), BF_S_OPS(2), BF_D_OPS(2), BF_S_OPS(3), BF_D_OPS(3));
+    }
+}
+#undef BF_RD
+#undef BF_RELOAD_HEAD
+#undef BF_RELOAD_TAIL
+#undef BF_RDD
+#undef BF_S_OPS
+#undef BF_D_OPS
+
+// acc += quad (pad) / acc += fma(h, D, S) (lerp) on the two register pairs of a segment.  asm so that it stays between
+// the reloads in program order (a C++ expression may be sunk below the next reload at the price of register copies).
+__device__ __forceinline__ void add_quad(f32x2 (&ac)[2], const Quad& q)
+{
+    // pad_and_sum.c:41-47   out[k] += s[k - p]
+    asm volatile("v_pk_add_f32 %[a0], %[a0], %[lo]\n\tv_pk_add_f32 %[a1], %[a1], %[hi]" : [a0] "+v"(ac[0]), [a1] "+v"(ac[1]) : [lo] "v"(q.lo), [hi] "v"(q.hi));
+}
+template <int HALF>   // which half of the SGPR pair `hp` holds this direction's weight
+__device__ __forceinline__ void lerp_quad(f32x2 (&ac)[2], const Quad& q, const Quad& d, unsigned long long hp)
+{
+    // lerp_and_sum.c:50-56  out[k] += s[i] + h * (s[i+1] - s[i]),  i = k - p - 1   (gcc contracts it into one fma)
+    // The weights of two neighbouring directions arrive as one aligned SGPR pair straight from s_load; op_sel picks the half.
+    f32x2 t0, t1;
+    if constexpr (HALF == 0) {
+        asm volatile("v_pk_fma_f32 %[t0], %[h], %[dl], %[ql] op_sel_hi:[0,1,1]\n\t"
+                     "v_pk_fma_f32 %[t1], %[h], %[dh], %[qh] op_sel_hi:[0,1,1]\n\t"
+                     "v_pk_add_f32 %[a0], %[a0], %[t0]\n\t"
+                     "v_pk_add_f32 %[a1], %[a1], %[t1]"
+                     : [a0] "+v"(ac[0]), [a1] "+v"(ac[1]), [t0] "=&v"(t0), [t1] "=&v"(t1)
+                     : [h] "s"(hp), [dl] "v"(d.lo), [dh] "v"(d.hi), [ql] "v"(q.lo), [qh] "v"(q.hi));
+    } else {
+        asm volatile("v_pk_fma_f32 %[t0], %[h], %[dl], %[ql] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                     "v_pk_fma_f32 %[t1], %[h], %[dh], %[qh] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                     "v_pk_add_f32 %[a0], %[a0], %[t0]\n\t"
+                     "v_pk_add_f32 %[a1], %[a1], %[t1]"
+                     : [a0] "+v"(ac[0]), [a1] "+v"(ac[1]), [t0] "=&v"(t0), [t1] "=&v"(t1)
+                     : [h] "s"(hp), [dl] "v"(d.lo), [dh] "v"(d.hi), [ql] "v"(q.lo), [qh] "v"(q.hi));
+    }
+}
+
 // One workgroup (16 waves, one per CU: it owns the LDS) walks a tile of directions in groups of kGroup; for each group
 // the frame's mics pass through LDS in chunks (each mic staged as 4 shifted copies, lerp also 4 copies of the first
 // difference), every wave accumulating its directions in registers across the chunks.  A chunk is consumed between
@@ -729,9 +899,8 @@ __global__ void __launch_bounds__(1024, 4) das_copies_kernel(BF_TABLE_PARAMS, KA
     static_assert(!FIR || NSEG == 1, "the FIR flavours use the one-segment geometry");
     static_assert(RS == 0 || RS == (FIR ? Geo<NSEG>::kRsFir : Geo<NSEG>::kRs), "fixed row stride");
     constexpr int A = (ALGO == ALGO_LERP) ? 2 : 1;   // arrays per mic: s (and D)
-    constexpr int DW = Geo<NSEG>::kDw, U = Geo<NSEG>::kBatch, kGroup = Geo<NSEG>::kGroup, kPark = Geo<NSEG>::kPark;
+    constexpr int DW = Geo<NSEG>::kDw, kGroup = Geo<NSEG>::kGroup, kPark = Geo<NSEG>::kPark;
     constexpr int SP = (NSEG > 1 && ALGO == ALGO_PAD) ? 2 : 1;   // (mic, segment) pairs a wave stages per chunk
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -950,94 +1119,100 @@ __global__ void __launch_bounds__(1024, 4) das_copies_kernel(BF_TABLE_PARAMS, KA
                     acc[j][0][1] = f32x2{o[2], o[3]};
                 }
             };
-            // One direction at a time, its staged mics in order, U mics x NSEG segments of reads in flight.
-            auto directions = [&](auto mcc_c) {
-                // MCC > 0: the chunk's mic count at compile time (a whole number of batches): straight-line code, no
-                // per-mic conditionals.  MCC == 0: any count, one uniform branch per batch.
-                constexpr int MCC = decltype(mcc_c)::value;
-                constexpr bool FULL = MCC > 0;
-                static_assert(MCC % U == 0, "whole batches");
+            // pad / lerp: mic-outer sweep over the wave's DW directions.  Neighbouring directions mostly share a mic's
+            // whole-sample delay (the delay changes by a fraction of a sample per grid step), and the LDS read depends on
+            // nothing else: the quad (and its difference quad) is re-read only when the offset differs from the previous
+            // direction's -- a wave-uniform test on two SGPRs.  On the reference's geometries that is 1.1 - 2.2 reads per
+            // 8 directions, which takes the LDS pipe out of the picture and leaves the adds.  Two mics advance together
+            // so that their reads overlap.
+            auto sweep = [&]() {
+                const int dw0 = g0 + wave * DW;                 // wave-uniform
+                if (dw0 >= tile_end) return;                    // this wave has no directions in the tile
+                const size_t grp = (size_t)(dw0 - a.dir_begin) / DW;
+                const int32_t* __restrict__ eg = dig + (grp * M + m0) * DW;
+                const float* __restrict__ hg = reinterpret_cast<const float*>(dig) + a.digest_h_off + (grp * M + m0) * DW;
+                // LDS byte address of this lane's quad column (the asm reads need the raw 32-bit LDS address)
+                const int lb = 16 * lane + (int)(unsigned)(size_t)((__attribute__((address_space(3))) char*)lds);
+                const int d_off = 16 * rs;                      // D copies sit 4 rows after the s copies
+                constexpr bool kLerp = ALGO == ALGO_LERP;
+                struct Entries { int e[DW]; unsigned long long hp[DW / 2]; };   // offsets; lerp weights as (even, odd) direction pairs
+                auto request = [&](Entries& t, int m) {
+                    // (reads past the chunk's last mic stay inside the slack-padded table and are dropped)
 #pragma unroll
-                for (int j = 0; j < DW; ++j) {
-                    const int d = g0 + wave * DW + j;           // wave-uniform
-                    if (d >= tile_end) continue;
-                    const size_t idx = (size_t)d * M + m0;
-                    // 16 entries unconditionally (the tables carry 64 bytes of slack) so the loads merge into wide s_loads
-                    int e[16];
-                    float hh[16];
+                    for (int j = 0; j < DW; ++j) t.e[j] = eg[m * DW + j];
 #pragma unroll
-                    for (int m = 0; m < 16; ++m) {
-                        e[m] = dig[idx + m];
-                        hh[m] = 0.0f;
-                        if constexpr (ALGO == ALGO_LERP) hh[m] = frac[idx + m];
+                    for (int j = 0; j < DW / 2; ++j) {
+                        t.hp[j] = 0;
+                        if constexpr (kLerp) t.hp[j] = *reinterpret_cast<const unsigned long long*>(hg + m * DW + 2 * j);   // 8-byte aligned: DW is even
                     }
-                    auto consume = [&](const float4& Sq, const float4& Dv, float h, f32x2 (&ac)[2]) {
-                        const f32x2 S01{Sq.x, Sq.y}, S23{Sq.z, Sq.w};
-                        if constexpr (ALGO == ALGO_PAD) {
-                            // pad_and_sum.c:41-47   out[k] += s[k - p]
-                            ac[0] += S01; ac[1] += S23;
-                        } else {
-                            // lerp_and_sum.c:50-56  out[k] += s[i] + h * (s[i+1] - s[i]),  i = k - p - 1
-                            const f32x2 h2{h, h}, D01{Dv.x, Dv.y}, D23{Dv.z, Dv.w};
-                            ac[0] += __builtin_elementwise_fma(h2, D01, S01);
-                            ac[1] += __builtin_elementwise_fma(h2, D23, S23);
+                };
+                // A three-stage pipeline over the mics, so that no wave ever sits on an LDS or scalar-load round trip:
+                //   mic m     its quads (requested one mic ago) are awaited, then consumed by the DW direction steps;
+                //   mic m + 1 its table entries (requested two mics ago) are used to request its first quads;
+                //   mic m + 2 its table entries are requested.
+                // Two quad sets alternate by mic parity, three entry sets rotate: six mics per loop trip, no register copies.
+                Entries E[3];
+                Quad S[2][NSEG], Dq[2][NSEG];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int sg = 0; sg < NSEG; ++sg) S[q][sg].lo = S[q][sg].hi = Dq[q][sg].lo = Dq[q][sg].hi = f32x2{0.0f, 0.0f};
+                // The cross-mic quad prefetch is used for one segment only: with more segments the 64 accumulators make the
+                // compiler spill, and a register with a read in flight must not be moved behind the asm statements' back.
+                constexpr bool kPipe = NSEG == 1;
+                request(E[0], 0);
+                request(E[1], 1);
+                if constexpr (kPipe) issue_quads<NSEG, kLerp>(S[0], Dq[0], E[0].e[0] & ~15, lb, d_off);
+                auto mic = [&](int m, auto pc, auto kc) {
+                    constexpr int P = kPipe ? decltype(pc)::value : 0, K = decltype(kc)::value, K1 = (K + 1) % 3, K2 = (K + 2) % 3;
+                    const Entries& cur = E[K];
+                    if constexpr (kPipe) {
+                        await_quads<NSEG>(S[P], Dq[P]);
+                        issue_quads<NSEG, kLerp>(S[P ^ 1], Dq[P ^ 1], E[K1].e[0] & ~15, lb, d_off);
+                        request(E[K2], m + 2);
+                    } else {
+                        request(E[K2], m + 2);
+                        reload_quads<NSEG, kLerp>(S[P], Dq[P], cur.e[0] & ~15, -1, lb, d_off);   // offsets are >= 0: -1 always loads (and waits)
+                    }
+                    auto stepj = [&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        if constexpr (j > 0) reload_quads<NSEG, kLerp>(S[P], Dq[P], cur.e[j], j == 1 ? (cur.e[0] & ~15) : cur.e[j - 1], lb, d_off);
+#pragma unroll
+                        for (int sg = 0; sg < NSEG; ++sg) {
+                            if constexpr (ALGO == ALGO_PAD) add_quad(acc[j][sg], S[P][sg]);
+                            else lerp_quad<j & 1>(acc[j][sg], S[P][sg], Dq[P][sg], cur.hp[j / 2]);
                         }
                     };
-                    if constexpr (FULL) {
-                        // software pipeline over the (mic, segment) units of this direction: R units' reads in flight,
-                        // each consumed unit's registers are refilled at once
-                        constexpr int R = 4, UNITS = MCC * NSEG;
-                        float4 S[R], Dq[R];
-                        auto issue = [&](int i, int slot) {
-                            const char* sp = lbase + e[i / NSEG] + 1024 * (i % NSEG);
-                            S[slot] = *reinterpret_cast<const float4*>(sp);
-                            if constexpr (ALGO == ALGO_LERP) Dq[slot] = *reinterpret_cast<const float4*>(sp + 16 * rs);   // D copies: 4 rows on
-                        };
-#pragma unroll
-                        for (int i = 0; i < R; ++i) issue(i, i);
-#pragma unroll
-                        for (int i = 0; i < UNITS; ++i) {
-                            consume(S[i % R], Dq[i % R], hh[i / NSEG], acc[j][i % NSEG]);
-                            if (i + R < UNITS) issue(i + R, i % R);
-                        }
-                    } else {
-#pragma unroll
-                        for (int mb = 0; mb < 16; mb += U) {
-                            if (mb >= mcc) break;
-                            float4 S[U][NSEG], Dq[U][NSEG];
-#pragma unroll
-                            for (int u = 0; u < U; ++u) {
-                                // a partial batch re-reads mic 0's row for the missing mics and drops the result
-                                const int eo = (mb + u < mcc) ? e[mb + u] : e[0];
-                                const char* sp = lbase + eo;
-#pragma unroll
-                                for (int sg = 0; sg < NSEG; ++sg) {
-                                    S[u][sg] = *reinterpret_cast<const float4*>(sp + 1024 * sg);
-                                    if constexpr (ALGO == ALGO_LERP) Dq[u][sg] = *reinterpret_cast<const float4*>(sp + 16 * rs + 1024 * sg);
-                                }
-                            }
-#pragma unroll
-                            for (int u = 0; u < U; ++u) {
-                                if (mb + u >= mcc) break;
-#pragma unroll
-                                for (int sg = 0; sg < NSEG; ++sg) consume(S[u][sg], Dq[u][sg], hh[mb + u], acc[j][sg]);
-                            }
-                        }
+                    stepj(std::integral_constant<int, 0>{});
+                    stepj(std::integral_constant<int, 1>{});
+                    stepj(std::integral_constant<int, 2>{});
+                    stepj(std::integral_constant<int, 3>{});
+                    if constexpr (DW == 8) {
+                        stepj(std::integral_constant<int, 4>{});
+                        stepj(std::integral_constant<int, 5>{});
+                        stepj(std::integral_constant<int, 6>{});
+                        stepj(std::integral_constant<int, 7>{});
                     }
+                };
+                using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+                for (int m = 0; m < mcc; m += 6) {             // (plain ifs, no early exit: keeps the register state of all paths identical)
+                    mic(m, I0{}, I0{});
+                    if (m + 1 < mcc) mic(m + 1, I1{}, I1{});
+                    if (m + 2 < mcc) mic(m + 2, I0{}, I2{});
+                    if (m + 3 < mcc) mic(m + 3, I1{}, I0{});
+                    if (m + 4 < mcc) mic(m + 4, I0{}, I1{});
+                    if (m + 5 < mcc) mic(m + 5, I1{}, I2{});
                 }
+                // nothing may stay in flight into registers the compiler is about to reuse
+                await_quads<NSEG>(S[0], Dq[0]);
+                await_quads<NSEG>(S[1], Dq[1]);
             };
-            // N <= 256: the chunk sizes the planner picks get straight-line code.  With more segments the 64 accumulator
-            // registers leave no room for the deeper read pipelining that buys (it spills), so only the branchy form.
             if constexpr (FIR) {
                 if (mcc == 16) fir_directions(std::integral_constant<int, 16>{});
                 else if (mcc == 8) fir_directions(std::integral_constant<int, 8>{});
                 else fir_directions(std::integral_constant<int, 0>{});
-            } else if constexpr (NSEG == 1) {
-                if (mcc == 16) directions(std::integral_constant<int, 16>{});
-                else if (mcc == 8) directions(std::integral_constant<int, 8>{});
-                else directions(std::integral_constant<int, 0>{});
             } else {
-                directions(std::integral_constant<int, 0>{});
+                sweep();
             }
         }
 
@@ -1119,6 +1294,20 @@ hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, in
             auto kernel = plan.row_stride == kRs && plan.lead == G::kLead ? copies::das_copies_kernel<ALGO, NSEG, kRs> : copies::das_copies_kernel<ALGO, NSEG, 0>;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
             if (e != hipSuccess) return e;
+            if constexpr (!kFir && NSEG == 1) {
+                // This variant keeps LDS reads in flight across asm statements (issue_quads / await_quads): sound only while
+                // the compiler neither spills nor copies those registers.  Spilling is checkable: refuse to run a build that
+                // uses scratch (copies would show in the bit-exact parity tests).
+                static int scratch_bytes[2] = {-1, -1};
+                int& sb = scratch_bytes[plan.row_stride == kRs && plan.lead == G::kLead ? 1 : 0];
+                if (sb < 0) {
+                    hipFuncAttributes fa{};
+                    e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel));
+                    if (e != hipSuccess) return e;
+                    sb = (int)fa.localSizeBytes;
+                }
+                if (sb != 0) return hipErrorInvalidDeviceFunction;
+            }
             // the digest rides in a pointer slot the algorithm does not use: taps (pad, lerp) or frac (hybrid)
             const float* dig = reinterpret_cast<const float*>(L.tab.digest);
             hipLaunchKernelGGL(kernel, grid, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole, kFir ? dig : L.tab.frac,
@@ -1176,6 +1365,12 @@ hipError_t launch_miso_algo(const DasLaunch& L, const KArgs& a, const DasPlan& p
     }
 }
 
+long long grouped_entries_for_args(const DasLaunch& L, const DasPlan& plan)
+{
+    const long long groups = ((long long)(L.dir_end - L.dir_begin) + plan.dpw - 1) / plan.dpw;
+    return groups * L.n_mics * plan.dpw;
+}
+
 KArgs make_args(const DasLaunch& L, const DasPlan& plan)
 {
     KArgs a{};
@@ -1188,6 +1383,7 @@ KArgs make_args(const DasLaunch& L, const DasPlan& plan)
     a.n_is_pow2 = (L.n_mics & (L.n_mics - 1)) == 0;
     a.inv_n = 1.0f / (float)L.n_mics;
     a.debug = L.debug;
+    a.digest_h_off = (plan.layout == 2 && L.algo == ALGO_LERP) ? grouped_entries_for_args(L, plan) : 0;
     return a;
 }
 
@@ -1295,13 +1491,32 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
     return 0;
 }
 
-hipError_t launch_digest(const int32_t* d_whole, int32_t* d_digest, long long entries, int n_mics, const DasPlan& plan, int algo, hipStream_t stream)
+namespace {
+long long grouped_entries(const DasLaunch& L, const DasPlan& plan) { return grouped_entries_for_args(L, plan); }
+}  // namespace
+
+size_t digest_elements(const DasLaunch& L, const DasPlan& plan)
+{
+    if (plan.layout != 2) return 0;
+    if (L.algo == ALGO_PAD) return (size_t)grouped_entries(L, plan);
+    if (L.algo == ALGO_LERP) return (size_t)(2 * grouped_entries(L, plan));    // offsets, then the lerp weights in the same order
+    if (L.algo == ALGO_HYBRID) return (size_t)L.n_dirs * (size_t)L.n_mics;
+    return 0;
+}
+
+hipError_t launch_digest(const DasLaunch& L, const DasPlan& plan, int32_t* d_digest, hipStream_t stream)
 {
     // what the kernel looks back by beyond the whole-sample delay: lerp reads s[k - p - 1], hybrid starts its window at
     // s[k - p - 1 - T/2] (T = 8)
-    const int arrays = (algo == ALGO_LERP) ? 2 : 1, bias = (algo == ALGO_LERP) ? 1 : (algo == ALGO_HYBRID) ? 5 : 0;
-    hipLaunchKernelGGL(digest_kernel, dim3(1024), dim3(256), 0, stream, d_whole, d_digest, entries, n_mics, plan.mic_chunk, arrays, plan.row_stride,
-                       plan.lead, bias);
+    const int arrays = (L.algo == ALGO_LERP) ? 2 : 1, bias = (L.algo == ALGO_LERP) ? 1 : (L.algo == ALGO_HYBRID) ? 5 : 0;
+    if (L.algo == ALGO_HYBRID) {
+        hipLaunchKernelGGL(digest_kernel, dim3(1024), dim3(256), 0, stream, L.tab.whole, d_digest, (long long)L.n_dirs * L.n_mics, L.n_mics, plan.mic_chunk,
+                           arrays, plan.row_stride, plan.lead, bias);
+    } else {
+        const long long entries = grouped_entries(L, plan);
+        hipLaunchKernelGGL(digest_grouped_kernel, dim3(1024), dim3(256), 0, stream, L.tab.whole, L.algo == ALGO_LERP ? L.tab.frac : nullptr, d_digest,
+                           entries, entries, L.n_mics, plan.dpw, L.dir_begin, L.dir_end, plan.mic_chunk, arrays, plan.row_stride, plan.lead, bias);
+    }
     return hipGetLastError();
 }
 
