@@ -834,16 +834,19 @@ __device__ __forceinline__ void issue_quads(Quad (&S)[NSEG], Quad (&D)[NSEG], in
                      : [e] "s"(e), [lb] "v"(lbase), [doff] "s"(d_off));
     }
 }
-// "the quads requested by issue_quads have arrived" (also drains outstanding scalar loads: same counter)
+// "the quads requested by issue_quads have arrived" (also drains outstanding scalar loads: same counter).  The wait is
+// the compiler-visible builtin, so that the compiler knows every earlier scalar load has landed and does not insert a
+// second, badly placed wait before the first use of a table entry; the empty asm ties the quad registers to this point.
 template <int NSEG>
 __device__ __forceinline__ void await_quads(Quad (&S)[NSEG], Quad (&D)[NSEG])
 {
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // vmcnt(63) expcnt(7) lgkmcnt(0)
     if constexpr (NSEG == 1) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : BF_S_OPS(0), BF_D_OPS(0));
+        asm volatile("" : BF_S_OPS(0), BF_D_OPS(0));
     } else if constexpr (NSEG == 2) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : BF_S_OPS(0), BF_D_OPS(0), BF_S_OPS(1), BF_D_OPS(1));
+        asm volatile("" : BF_S_OPS(0), BF_D_OPS(0), BF_S_OPS(1), BF_D_OPS(1));
     } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : BF_S_OPS(0), BF_D_OPS(0), BF_S_OPS(1), BF_D_OPS(1), BF_S_OPS(2), BF_D_OPS(2), BF_S_OPS(3), BF_D_OPS(3));
+        asm volatile("" : BF_S_OPS(0), BF_D_OPS(0), BF_S_OPS(1), BF_D_OPS(1), BF_S_OPS(2), BF_D_OPS(2), BF_S_OPS(3), BF_D_OPS(3));
     }
 }
 #undef BF_RD
