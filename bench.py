@@ -34,7 +34,6 @@ WORKLOADS = {
     "cfg5": (256, 4, 1024, 361, 361, 8),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-LDS_PEAK_GBS = 256 * 256 * 2.4  # ds_read_b128: 256 B/clk/CU x 256 CUs x 2.4 GHz = 157 TB/s (MI355X_MICROARCH.md, LDS table)
 
 
 def algorithmic_bytes_per_frame(algo, M, N, D, T):
@@ -282,8 +281,12 @@ def main():
         alg_bytes = frames_global * (sig_bytes + (bytes_frame - sig_bytes) * share)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         macs = frames_global * (hi - lo) * M * N
-        # LDS bytes the kernel reads per MAC: pad 4 (one sample); lerp 8 (sample + its difference); FIR flavours 4*T
-        lds_bytes = macs * 4 * (2 if args.algo == "lerp" else T if args.algo in ("hybrid", "fir_vec", "fir_naive") else 1)
+        # The honest limiter is the VALU: per (direction, mic, 256-sample segment) step a wave issues 2 v_pk_add_f32 (pad),
+        # 2 v_pk_fma_f32 + 2 v_pk_add_f32 (lerp) or 32 v_fmac_f32 (8-tap FIR) plus a scalar compare/branch.  Floors measured
+        # with scripts/dev/valu_probe.hip on MI355X (16 waves per CU, ns per step per CU): the instruction mix alone.
+        steps = frames_global * (hi - lo) * M * ((N + 255) // 256)
+        floor_ns = {"pad": 1.12, "lerp": 2.12}.get(args.algo, 32 * 1.18 / 4)
+        step_ns = kernel_ms * 1e6 * 256 / steps              # 256 CUs
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -301,10 +304,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": ("copies::das_copies_kernel<%s>" if args.algo in ("pad", "lerp") and N <= 256 else "das_mimo_kernel<%s>") % args.algo, "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "LDS-gather kernel: the tables stay L2-resident across the frames of a launch and the binding resources are "
-                                 "VALU issue and LDS reads, not HBM (DESIGN.md section 5)",
-                         "lds": {"achieved": lds_bytes / (kernel_ms * 1e-3) / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
-                                 "frac": lds_bytes / (kernel_ms * 1e-3) / 1e9 / LDS_PEAK_GBS},
+                         "note": "gather-accumulate kernel: tables stay L2-resident across the frames of a launch, sample quads are re-read "
+                                 "from LDS only when a direction's delay differs from its neighbour's; the binding resource is VALU issue, "
+                                 "not HBM (DESIGN.md section 5)",
+                         "valu": {"ns_per_step_per_cu": step_ns, "floor_ns_per_step_per_cu": floor_ns, "frac": floor_ns / step_ns,
+                                  "floor": "instruction mix alone at 16 waves/CU, scripts/dev/valu_probe.hip"},
                          "gmacs_per_s": macs / (kernel_ms * 1e-3) / 1e9},
         }
         if world == 1 and not args.no_cpu_baseline and args.algo in ("pad", "lerp", "hybrid"):
