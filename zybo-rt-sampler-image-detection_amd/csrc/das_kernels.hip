@@ -672,7 +672,7 @@ __global__ void __launch_bounds__(256) digest_grouped_kernel(const int32_t* __re
 
 namespace copies {
 
-constexpr int kWaves = 16;       // waves per workgroup
+constexpr int kWaves = 16;       // waves per workgroup (8 for pad / lerp at N <= 256: two workgroups per CU cover each other's barriers)
 
 __device__ __forceinline__ float dpp_prev(float x)   // lane-1's value, 0 in lane 0
 {
@@ -690,7 +690,6 @@ __device__ __forceinline__ float lane_value(float x, int l) { return __int_as_fl
 template <int NSEG>
 struct Geo {
     static constexpr int kDw = NSEG == 1 ? 8 : NSEG == 2 ? 8 : 4;   // directions per wave
-    static constexpr int kGroup = kDw * kWaves;                      // directions per workgroup pass
     static constexpr int kBatch = 4 / NSEG;                          // mics whose reads are in flight together
     static constexpr int kLead = NSEG == 1 ? 48 : 64;                // zero prefix of the fixed-stride variant
     static constexpr int kRs = NSEG * 256 + kLead;                   // its row stride
@@ -895,15 +894,15 @@ __device__ __forceinline__ void lerp_quad(f32x2 (&ac)[2], const Quad& q, const Q
 // per (direction, mic)), fetched with s_load_dwordx16 like the lerp weights in `frac`.  Per (direction, mic, segment)
 // the wave issues  pad: 1 ds_read_b128 + 2 v_pk_add_f32;  lerp: 2 ds_read_b128 + 2 v_pk_fma_f32 + 2 v_pk_add_f32, plus
 // one v_add per (direction, mic) for the address (two for lerp with a run-time row stride).
-template <int ALGO, int NSEG, int RS>
-__global__ void __launch_bounds__(1024, 4) das_copies_kernel(BF_TABLE_PARAMS, KArgs a)
+template <int ALGO, int NSEG, int RS, int W>
+__global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, KArgs a)
 {
     constexpr bool FIR = ALGO == ALGO_HYBRID || ALGO == ALGO_FIR_NAIVE || ALGO == ALGO_FIR_VEC;   // 8 taps, N <= 256
     static_assert(!FIR || NSEG == 1, "the FIR flavours use the one-segment geometry");
     static_assert(RS == 0 || RS == (FIR ? Geo<NSEG>::kRsFir : Geo<NSEG>::kRs), "fixed row stride");
     constexpr int A = (ALGO == ALGO_LERP) ? 2 : 1;   // arrays per mic: s (and D)
-    constexpr int DW = Geo<NSEG>::kDw, kGroup = Geo<NSEG>::kGroup, kPark = Geo<NSEG>::kPark;
-    constexpr int SP = (NSEG > 1 && ALGO == ALGO_PAD) ? 2 : 1;   // (mic, segment) pairs a wave stages per chunk
+    constexpr int DW = Geo<NSEG>::kDw, kGroup = DW * W, kPark = Geo<NSEG>::kPark;   // kGroup: directions per workgroup pass
+    constexpr int SP = ((NSEG > 1 && ALGO == ALGO_PAD) ? 32 : 16) / W;   // (mic, segment) pairs a wave stages per chunk
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -921,20 +920,20 @@ __global__ void __launch_bounds__(1024, 4) das_copies_kernel(BF_TABLE_PARAMS, KA
     const int32_t* __restrict__ dig = reinterpret_cast<const int32_t*>(FIR ? frac : taps);
     const int slot_floats = A * 4 * rs;   // floats per staged mic
 
-    // Rows of `signals` this wave stages: pair index pr = wave + 16 i  <->  chunk mic pr / NSEG, segment pr % NSEG.
+    // Rows of `signals` this wave stages: pair index pr = wave + W i  <->  chunk mic pr / NSEG, segment pr % NSEG.
     // The mic ids of the first 64 chunks are loaded once (lane c holds chunk c's) so that the per-chunk prefetch is a
     // single independent load, not a load that waits for an index load.
     int vmic[SP];
 #pragma unroll
     for (int i = 0; i < SP; ++i) {
-        const int cm = (wave + 16 * i) / NSEG;
+        const int cm = (wave + W * i) / NSEG;
         vmic[i] = 0;
         if (lane < a.n_chunks && cm < mc && lane * mc + cm < M) vmic[i] = mics[lane * mc + cm];
     }
     auto fetch = [&](int ch, int mcc, Staged (&st)[SP]) {
 #pragma unroll
         for (int i = 0; i < SP; ++i) {
-            const int pr = wave + 16 * i, cm = pr / NSEG, seg = pr % NSEG;
+            const int pr = wave + W * i, cm = pr / NSEG, seg = pr % NSEG;
             st[i].v = make_float4(0.f, 0.f, 0.f, 0.f);
             st[i].edge = 0.0f;
             if (cm < mcc) {
@@ -960,7 +959,7 @@ __global__ void __launch_bounds__(1024, 4) das_copies_kernel(BF_TABLE_PARAMS, KA
     auto stage = [&](int mcc, const Staged (&st)[SP]) {
 #pragma unroll
         for (int i = 0; i < SP; ++i) {
-            const int pr = wave + 16 * i, cm = pr / NSEG, seg = pr % NSEG;
+            const int pr = wave + W * i, cm = pr / NSEG, seg = pr % NSEG;
             if (cm >= mcc) continue;
             float* row0 = lds + cm * slot_floats;
             const int col = lead + 256 * seg;
@@ -1062,22 +1061,22 @@ __global__ void __launch_bounds__(1024, 4) das_copies_kernel(BF_TABLE_PARAMS, KA
                     float o[4] = {acc[j][0][0].x, acc[j][0][0].y, acc[j][0][1].x, acc[j][0][1].y};
                     auto consume = [&](const float4 (&hq)[2], const float4 (&q)[3], int pp) {
                         const float h[8] = {hq[0].x, hq[0].y, hq[0].z, hq[0].w, hq[1].x, hq[1].y, hq[1].z, hq[1].w};
-                        const float W[12] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w};
+                        const float Wn[12] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w};
                         if constexpr (ALGO == ALGO_HYBRID) {
                             // output j (sample 4 lane + j) is live for 4 lane + j > p: the first n_j = (p + 4 - j) >> 2 lanes are not
                             auto mask = [](int n) -> unsigned long long { return n >= 64 ? 0ull : (~0ull << n); };
-                            fir8_masked(o, W, h, mask((pp + 4) >> 2), mask((pp + 3) >> 2), mask((pp + 2) >> 2), mask((pp + 1) >> 2));
+                            fir8_masked(o, Wn, h, mask((pp + 4) >> 2), mask((pp + 3) >> 2), mask((pp + 2) >> 2), mask((pp + 1) >> 2));
                         } else if constexpr (ALGO == ALGO_FIR_NAIVE) {
                             // convolve_and_sum.c:197-211  out[i] += h[t] * padded[i + t], t in order (fma chain into out)
 #pragma unroll
                             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                                for (int t = 0; t < 8; ++t) o[jj] = __fmaf_rn(h[t], W[jj + t], o[jj]);
+                                for (int t = 0; t < 8; ++t) o[jj] = __fmaf_rn(h[t], Wn[jj + t], o[jj]);
                         } else {
                             // convolve_and_sum.c:158-192 + sum8 :132-153 with one AVX block: eight plain products, fixed tree, out +=
 #pragma unroll
                             for (int jj = 0; jj < 4; ++jj) {
-                                const float* x = W + jj;
+                                const float* x = Wn + jj;
                                 const float q0 = x[0] * h[0] + x[4] * h[4], q1 = x[1] * h[1] + x[5] * h[5];
                                 const float q2 = x[2] * h[2] + x[6] * h[6], q3 = x[3] * h[3] + x[7] * h[7];
                                 o[jj] += (q0 + q2) + (q1 + q3);
@@ -1222,8 +1221,8 @@ __global__ void __launch_bounds__(1024, 4) das_copies_kernel(BF_TABLE_PARAMS, KA
         // ---- k-ordered mean power (pad_and_sum.c:120-128): the waves park the squared means of their directions
         // (row = direction; the rows alias the chunk buffer; a.pbw waves at a time when a group's rows outgrow it),
         // then one direction per lane runs the sequential sum: 64 chains per instruction, coalesced image stores.
-        const int pw_waves = NSEG == 1 ? kWaves : a.pbw;   // N <= 256: the planner sizes LDS for the whole group's rows
-        for (int w0 = 0; w0 < kWaves; w0 += pw_waves) {
+        const int pw_waves = NSEG == 1 ? W : a.pbw;   // N <= 256: the planner sizes LDS for the whole group's rows
+        for (int w0 = 0; w0 < W; w0 += pw_waves) {
             __syncthreads();
             if (wave >= w0 && wave < w0 + pw_waves) {
                 // mean over the mics: a power-of-two count multiplies (exact), anything else divides like the reference;
@@ -1294,15 +1293,20 @@ hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, in
             constexpr int NSEG = NC / 4;
             using G = copies::Geo<NSEG>;
             constexpr int kRs = kFir ? G::kRsFir : G::kRs;
-            auto kernel = plan.row_stride == kRs && plan.lead == G::kLead ? copies::das_copies_kernel<ALGO, NSEG, kRs> : copies::das_copies_kernel<ALGO, NSEG, 0>;
+            const bool fixed = plan.row_stride == kRs && plan.lead == G::kLead;
+            auto kernel = fixed ? copies::das_copies_kernel<ALGO, NSEG, kRs, copies::kWaves> : copies::das_copies_kernel<ALGO, NSEG, 0, copies::kWaves>;
+            if constexpr (!kFir && NSEG == 1) {
+                if (plan.waves == 8) kernel = fixed ? copies::das_copies_kernel<ALGO, NSEG, kRs, 8> : copies::das_copies_kernel<ALGO, NSEG, 0, 8>;
+            }
+            if (plan.waves != copies::kWaves && !(plan.waves == 8 && !kFir && NSEG == 1)) return hipErrorInvalidValue;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
             if (e != hipSuccess) return e;
             if constexpr (!kFir && NSEG == 1) {
                 // This variant keeps LDS reads in flight across asm statements (issue_quads / await_quads): sound only while
                 // the compiler neither spills nor copies those registers.  Spilling is checkable: refuse to run a build that
                 // uses scratch (copies would show in the bit-exact parity tests).
-                static int scratch_bytes[2] = {-1, -1};
-                int& sb = scratch_bytes[plan.row_stride == kRs && plan.lead == G::kLead ? 1 : 0];
+                static int scratch_bytes[4] = {-1, -1, -1, -1};
+                int& sb = scratch_bytes[(fixed ? 1 : 0) + (plan.waves == 8 ? 2 : 0)];
                 if (sb < 0) {
                     hipFuncAttributes fa{};
                     e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel));
@@ -1454,20 +1458,26 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
         // a chunk: as many mics as fit beside nothing else in 156 KiB, at most 16 (one s_load of table entries) and at
         // most what the 16 waves stage in one go (one (mic, segment) pair each; two for pad with several segments)
         const int stage_pairs = 16 * ((nseg > 1 && L.algo == ALGO_PAD) ? 2 : 1);
-        int mc = (int)((size_t)156 * 1024 / slot_bytes);
+        // One 16-wave workgroup per CU with (nearly) the whole LDS.  pad / lerp at N <= 256 also come as 8-wave workgroups
+        // (two per CU, 78 KiB each): twice the staging per direction, so only for grids too coarse to fill 16 waves' 128
+        // directions (cfg1: 121 directions, 637K -> 961K frames/s).  (cfg2, 190 frames: 16 waves 80.0K, 8 waves 72.0K.)
+        const int waves = (plain && nseg == 1 && (L.dir_end - L.dir_begin) < 256) ? 8 : copies::kWaves;
+        const size_t budget = waves == 8 ? (size_t)78 * 1024 : (size_t)156 * 1024;
+        int mc = (int)(budget / slot_bytes);
         if (mc > stage_pairs / nseg) mc = stage_pairs / nseg;
         mc = mc >= 16 ? 16 : mc >= 8 ? 8 : mc >= 4 ? 4 : mc >= 2 ? 2 : mc;
         if (mc < 1) return fail(3);
         if (mc > L.n_mics) mc = L.n_mics;
         p.mic_chunk = mc; p.n_chunks = (L.n_mics + mc - 1) / mc;
-        p.waves = copies::kWaves; p.dpw = dw; p.srow = nseg * 256 + 4;
+        p.waves = waves; p.dpw = dw; p.srow = nseg * 256 + 4;
         p.scratch_off = 0;
         const size_t buf = slot_bytes * (size_t)mc;
         const size_t wave_rows = (size_t)dw * p.srow * sizeof(float);          // the parked rows of one wave
         p.lds_bytes = buf > 2 * wave_rows ? buf : 2 * wave_rows;
-        if (nseg == 1 && p.lds_bytes < 16 * wave_rows) p.lds_bytes = 16 * wave_rows;   // N <= 256: the whole group parks at once
+        if (nseg == 1 && p.lds_bytes < waves * wave_rows) p.lds_bytes = waves * wave_rows;   // N <= 256: the whole group parks at once
         int pw = (int)(p.lds_bytes / wave_rows);                                 // waves that park together (power of two)
         p.pbw = pw >= 16 ? 16 : pw >= 8 ? 8 : pw >= 4 ? 4 : 2;
+        if (p.pbw > waves) p.pbw = waves;
     }
     if (p.layout != 2) {
         p.scratch_off = round_up(p.mic_chunk * p.row_stride, 4);
