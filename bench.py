@@ -75,8 +75,39 @@ def cpu_baseline(workload, algo, budget_s=12.0):
         el = time.perf_counter() - t0
         if el >= budget_s or frames >= 400:
             break
-    return {"value": frames / el, "unit": "frames/s", "cores": 1, "kind": eng.kind,
-            "sample": "%d frames of %s (%s, S2 noise), kernel only, tables preloaded, %.1f s" % (frames, workload, algo, el)}
+    out = {"value": frames / el, "unit": "frames/s", "cores": 1, "kind": eng.kind,
+           "sample": "%d frames of %s (%s, S2 noise), kernel only, tables preloaded, %.1f s" % (frames, workload, algo, el)}
+    # SURVEY.md section 8d also asks for the box's whole CPU: one independent replica of the same loop per host core
+    # (forked here, before anything has touched the GPU; the loaded tables are inherited)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    per = max(8, min(50000, int(frames * 6.0 / max(el, 1e-3))))          # about 6 s per replica
+    pipes = []
+    t0 = time.perf_counter()
+    for _ in range(cores):
+        r, w = os.pipe()
+        pid = os.fork()
+        if pid == 0:
+            os.close(r)
+            t1 = time.perf_counter()
+            for _k in range(per):
+                fn(*args)
+            os.write(w, ("%d %.6f" % (per, time.perf_counter() - t1)).encode())
+            os._exit(0)
+        os.close(w)
+        pipes.append((pid, r))
+    done = 0
+    for pid, r in pipes:
+        msg = os.read(r, 64).decode().split()
+        os.close(r)
+        os.waitpid(pid, 0)
+        done += int(msg[0]) if msg else 0
+    wall = time.perf_counter() - t0
+    out["all_cores"] = {"value": done / wall, "unit": "frames/s", "cores": cores,
+                        "sample": "%d replicas x %d frames, wall %.1f s (includes fork)" % (cores, per, wall)}
+    return out
 
 
 def timed(fn, torch, iters, warm=2):
@@ -147,6 +178,11 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
+
+    # the CPU baseline forks replicas: run it before anything initialises the GPU in this process
+    cpu_line = None
+    if world == 1 and not args.no_cpu_baseline and args.algo in ("pad", "lerp", "hybrid"):
+        cpu_line = cpu_baseline(args.workload, args.algo)
 
     import torch
     import torch.distributed as dist
@@ -311,8 +347,8 @@ def main():
                                   "floor": "instruction mix alone at 16 waves/CU, scripts/dev/valu_probe.hip"},
                          "gmacs_per_s": macs / (kernel_ms * 1e-3) / 1e9},
         }
-        if world == 1 and not args.no_cpu_baseline and args.algo in ("pad", "lerp", "hybrid"):
-            line["cpu_baseline"] = cpu_baseline(args.workload, args.algo)
+        if cpu_line is not None:
+            line["cpu_baseline"] = cpu_line
         if world == 1 and not args.no_extras and args.workload == "cfg2":
             try:
                 line["extra"] = extras(torch, nat, delays, mics, dev)
