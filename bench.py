@@ -83,7 +83,8 @@ def cpu_baseline(workload, algo, budget_s=12.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    per = max(8, min(50000, int(frames * 6.0 / max(el, 1e-3))))          # about 6 s per replica
+    cores = max(1, min(cores, int(os.environ.get("BF_BENCH_CPU_REPLICAS", "16"))))   # a one-GPU box's CPU share is 16 cores
+    per = max(8, min(50000, int(frames * 4.0 / max(el, 1e-3))))          # about 4 s per replica
     pipes = []
     t0 = time.perf_counter()
     for _ in range(cores):
