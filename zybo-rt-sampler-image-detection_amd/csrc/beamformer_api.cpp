@@ -76,6 +76,8 @@ struct State {
     DevBuf<float> d_frame, d_image, d_out, d_init, d_one_taps, d_one_frac;
     DevBuf<int32_t> d_mics, d_one_whole;
     DevBuf<float> fd_work;               // partial planes of the bin-reducing GEMMs (bf::fd_workspace_floats)
+    DevBuf<float> fd_tw;                 // twiddles of the MFMA DFT for (N, bin_lo, n_bins) = fd_tw_key
+    long long fd_tw_key = -1;
     std::vector<int> mics_host;          // what d_mics currently holds
     std::vector<float> published;        // bf_publish_frame / get_data
     std::vector<int> disabled_mics;      // get_data's dead-microphone rows
@@ -884,7 +886,14 @@ int bf_fd_dft_device(const float* d_frames, int m_total, int frames, const int* 
     int max_row = 0;
     if (!upload_mics(adaptive_array, n, &max_row)) return -1;
     if (max_row >= m_total) { set_error("bf_fd_dft_device: adaptive_array names row %d but frames have %d rows", max_row, m_total); return -1; }
-    return HIP_OK(bf::launch_fd_dft(d_frames, s.d_mics.p, m_total, s.sz.n_samples, frames, n, bin_lo, n_bins, d_xre_mf, d_xim_mf, d_xre_fm, d_xim_fm, st)) ? 0 : -1;
+    const long long key = ((long long)s.sz.n_samples << 40) ^ ((long long)bin_lo << 20) ^ n_bins;
+    if (s.fd_tw_key != key || !s.fd_tw.p) {
+        if (!HIP_OK(s.fd_tw.reserve(bf::fd_twiddle_floats(s.sz.n_samples, n_bins)))) return -1;
+        if (!HIP_OK(bf::launch_fd_twiddles(s.sz.n_samples, bin_lo, n_bins, s.fd_tw.p, st))) return -1;
+        s.fd_tw_key = key;
+    }
+    return HIP_OK(bf::launch_fd_dft(d_frames, s.d_mics.p, m_total, s.sz.n_samples, frames, n, bin_lo, n_bins, s.fd_tw.p, d_xre_mf, d_xim_mf, d_xre_fm, d_xim_fm,
+                                    st)) ? 0 : -1;
 }
 
 int bf_fd_das_power_device(const float* d_xre_mf, const float* d_xim_mf, const float* d_are, const float* d_aim, int frames, int n_mics, int n_dirs,

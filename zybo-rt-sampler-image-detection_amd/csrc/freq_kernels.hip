@@ -278,6 +278,83 @@ __global__ void __launch_bounds__(256) reduce_planes_kernel(const float* __restr
     }
 }
 
+// ---- DFT on the matrix cores.  X[k][r] = sum_n W[n][k] s[r][n] over the rows r = (frame, mic): a real GEMM per plane
+// (cos / -sin twiddles), 32 rows x all bins per wave.  The twiddles are built once per (N, bin range) in float64 with the
+// exact angle reduction (k n mod N) and staged through LDS in chunks of 64 samples; the signal operand is read straight
+// from the frames (each lane walks its own row).  Writes both layouts the GEMMs need: [K][M][F] and [K][F][M].
+__global__ void __launch_bounds__(256) twiddle_kernel(float* __restrict__ wc, float* __restrict__ ws, int n_samples, int bin_lo, int n_bins, int kp)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_samples * kp; i += gridDim.x * blockDim.x) {
+        const int n = i / kp, t = i - n * kp;
+        float c = 0.0f, sn = 0.0f;
+        if (t < n_bins) {
+            const long long idx = ((long long)(bin_lo + t) * n) % n_samples;
+            const double ang = -2.0 * 3.14159265358979323846 * (double)idx / (double)n_samples;
+            c = (float)cos(ang);
+            sn = (float)sin(ang);
+        }
+        wc[i] = c;
+        ws[i] = sn;
+    }
+}
+
+template <int KT>   // 32-bin tiles per wave (bins padded to 32 KT)
+__global__ void __launch_bounds__(256) dft_mfma_kernel(const float* __restrict__ frames, const int32_t* __restrict__ mics, int m_total, int n_samples,
+                                                       int n_frames, int n_mics, int n_bins, const float* __restrict__ wc, const float* __restrict__ ws,
+                                                       float* __restrict__ xre_mf, float* __restrict__ xim_mf, float* __restrict__ xre_fm,
+                                                       float* __restrict__ xim_fm)
+{
+    constexpr int KP = 32 * KT, CH = 64;        // padded bins; samples per staged twiddle chunk
+    extern __shared__ float tw[];               // [2][CH][KP]
+    float* tc = tw;
+    float* ts = tw + CH * KP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const long long rows = (long long)n_frames * n_mics;
+    const long long r = ((long long)blockIdx.x * 4 + wave) * 32 + li;       // this lane's row (as the B operand's column)
+    const bool r_ok = r < rows;
+    const int f = r_ok ? (int)(r / n_mics) : 0, m = r_ok ? (int)(r - (long long)f * n_mics) : 0;
+    const float* row = frames + ((size_t)f * m_total + (r_ok ? mics[m] : 0)) * n_samples;
+    f32x16 are_[KT], aim_[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { are_[t][q] = 0.0f; aim_[t][q] = 0.0f; }
+    for (int n0 = 0; n0 < n_samples; n0 += CH) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < CH * KP; i += blockDim.x) {
+            const int n = n0 + i / KP;
+            tc[i] = n < n_samples ? wc[(size_t)n0 * KP + i] : 0.0f;
+            ts[i] = n < n_samples ? ws[(size_t)n0 * KP + i] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int s2 = 0; s2 < CH / 2; ++s2) {
+            const int n = n0 + 2 * s2 + lk;
+            const float b = (r_ok && n < n_samples) ? row[n] : 0.0f;
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                const float c = tc[(2 * s2 + lk) * KP + 32 * t + li];
+                const float sn = ts[(2 * s2 + lk) * KP + 32 * t + li];
+                are_[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(c, b, are_[t], 0, 0, 0);
+                aim_[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sn, b, aim_[t], 0, 0, 0);
+            }
+        }
+    }
+    if (!r_ok) return;
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int k = 32 * t + acc_row(q, lane);
+            if (k < n_bins) {
+                const size_t mf = ((size_t)k * n_mics + m) * n_frames + f, fm = ((size_t)k * n_frames + f) * n_mics + m;
+                xre_mf[mf] = are_[t][q]; xim_mf[mf] = aim_[t][q];
+                xre_fm[fm] = are_[t][q]; xim_fm[fm] = aim_[t][q];
+            }
+        }
+}
+
 // X[k][.] = sum_n s[n] exp(-2 pi j k n / N) for the bins [bin_lo, bin_hi) (numpy.fft.rfft semantics), direct DFT with an
 // LDS twiddle table.  One workgroup per (frame, mic); thread t owns bin bin_lo + t.  Writes both operand layouts the
 // GEMMs need: [K][M][F] (mic-major, frames contiguous) and [K][F][M] (frame-major, mics contiguous).
@@ -432,12 +509,42 @@ hipError_t launch_fd_steering(const double* d_tau, const double* d_freq, int n_d
     return hipGetLastError();
 }
 
-hipError_t launch_fd_dft(const float* d_frames, const int32_t* d_mics, int m_total, int n_samples, int n_frames, int n_mics, int bin_lo, int n_bins,
-                         float* xre_mf, float* xim_mf, float* xre_fm, float* xim_fm, hipStream_t stream)
+size_t fd_twiddle_floats(int n_samples, int n_bins) { return (size_t)2 * n_samples * ((n_bins + 31) / 32 * 32); }
+
+hipError_t launch_fd_twiddles(int n_samples, int bin_lo, int n_bins, float* d_tw, hipStream_t stream)
 {
-    hipLaunchKernelGGL(dft_kernel, dim3((unsigned)(n_frames * n_mics)), dim3(128), (size_t)3 * n_samples * sizeof(float), stream, d_frames, d_mics, m_total,
-                       n_samples, n_frames, n_mics, bin_lo, n_bins, xre_mf, xim_mf, xre_fm, xim_fm);
+    const int kp = (n_bins + 31) / 32 * 32;
+    hipLaunchKernelGGL(twiddle_kernel, dim3(256), dim3(256), 0, stream, d_tw, d_tw + (size_t)n_samples * kp, n_samples, bin_lo, n_bins, kp);
     return hipGetLastError();
+}
+
+hipError_t launch_fd_dft(const float* d_frames, const int32_t* d_mics, int m_total, int n_samples, int n_frames, int n_mics, int bin_lo, int n_bins,
+                         const float* d_tw, float* xre_mf, float* xim_mf, float* xre_fm, float* xim_fm, hipStream_t stream)
+{
+    const int kt = (n_bins + 31) / 32;
+    if (d_tw == nullptr || kt > 4) {
+        // more than 128 bins (or no twiddle table): the plain kernel, one workgroup per (frame, mic)
+        hipLaunchKernelGGL(dft_kernel, dim3((unsigned)(n_frames * n_mics)), dim3(128), (size_t)3 * n_samples * sizeof(float), stream, d_frames, d_mics, m_total,
+                           n_samples, n_frames, n_mics, bin_lo, n_bins, xre_mf, xim_mf, xre_fm, xim_fm);
+        return hipGetLastError();
+    }
+    const int kp = kt * 32;
+    const float* wc = d_tw;
+    const float* ws = d_tw + (size_t)n_samples * kp;
+    const long long rows = (long long)n_frames * n_mics;
+    const dim3 grid((unsigned)((rows + 127) / 128));
+    const size_t lds = (size_t)2 * 64 * kp * sizeof(float);
+    auto go = [&](auto kernel) -> hipError_t {
+        hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, d_frames, d_mics, m_total, n_samples, n_frames, n_mics, n_bins, wc, ws, xre_mf, xim_mf, xre_fm,
+                           xim_fm);
+        return hipGetLastError();
+    };
+    switch (kt) {
+        case 1: return go(dft_mfma_kernel<1>);
+        case 2: return go(dft_mfma_kernel<2>);
+        case 3: return go(dft_mfma_kernel<3>);
+        default: return go(dft_mfma_kernel<4>);
+    }
 }
 
 namespace {
