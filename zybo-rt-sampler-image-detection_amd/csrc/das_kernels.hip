@@ -4,21 +4,24 @@
 //   for every frame f and steering direction d:   out_d[k] = sum_m delay_{d,m}( signals[f][mic_m][.] )[k]
 //                                                  image[f][d] = (1/N) * sum_k (out_d[k] / M)^2
 // The reference walks directions, then mics, then samples on one CPU thread.  Here:
-//   * one WORKGROUP owns a tile of directions of one frame and keeps that frame's microphone block in LDS
-//     (mic rows zero-extended on both sides so that a delayed read never needs a bounds test);
-//   * one WAVE owns one direction at a time; lane l owns samples l, l+64, l+128, ... of out_d (registers);
-//   * the per-(direction, mic) delay / interpolation weight / FIR taps are wave-uniform, so they are fetched
-//     with scalar loads (s_load_*) straight from the table row in HBM/L2 -- no VGPR or LDS traffic for tables;
-//   * the inner loop per (direction, mic) is NC conflict-free ds_read_b32 + NC VALU accumulations, in the
-//     reference's mic order and with the reference's operation order, so out_d[k] is bit-identical to the
-//     CPU result; only the final sum over k is a tree (wave reduction) instead of a sequential loop;
-//   * when a frame's mic block does not fit in LDS the mics are staged in chunks and a wave carries DPW
-//     directions' accumulators across the chunks.
+//   * one WORKGROUP owns a tile of directions of one frame and passes that frame's microphone rows through LDS
+//     (zero-extended so that a delayed read never needs a bounds test);
+//   * one WAVE carries a few directions' out_d in registers across the mics; the per-(direction, mic) delay /
+//     interpolation weight / FIR taps are wave-uniform;
+//   * mic order and operation order are the reference's, and the final sum over k is sequential in k (rows parked in
+//     LDS, one lane per direction), so the images are bit-identical to the CPU result.
+// Two families of kernels (DESIGN.md section 4.1 has the measurements behind each choice):
+//   * das_mimo_kernel / das_miso_kernel ("strided": lane l owns samples l, l+64, ...): any N <= 1024, any tap count,
+//     single beams; table entries by vector load + v_readlane.  The first implementation; now the general fallback.
+//   * copies::das_copies_kernel ("shifted copies": four copies of every staged row shifted by 0..3 samples, lane l owns
+//     the aligned quad 4l..4l+3): pad / lerp for 128 < N <= 1024 and the 8-tap FIR flavours for N <= 256 -- the kernels
+//     every BASELINE configuration runs.  pad / lerp sweep a mic over the wave's 8 directions and re-read its quad from
+//     LDS only when the delay changes from one direction to the next.
 // Workgroup id -> (tile, frame) keeps tile % 8 == id % 8, i.e. all frames' workgroups of one direction tile
 // land on one XCD and re-read that tile's table slice from the XCD's own L2.
 //
-// Roofline: gather-accumulate, no MFMA.  LDS read rate (ds_read_b32: 128 B/clk/CU) bounds it long before HBM;
-// see DESIGN.md for the byte/flop accounting.
+// Roofline: gather-accumulate, no MFMA, not HBM-bound (tables and samples are reused out of L2 / LDS); the binding
+// resource is VALU issue.  See DESIGN.md section 5 for the byte / instruction accounting.
 #include "das_kernels.h"
 
 #include <type_traits>
@@ -606,21 +609,18 @@ __global__ void __launch_bounds__(64) das_miso_kernel(BF_TABLE_PARAMS, const flo
 }
 
 // ==================================================================================================
-// "Shifted-copies" layout: pad and lerp for blocks of up to 256 samples (the reference's N_SAMPLES).
+// "Shifted-copies" layout (copies::das_copies_kernel below).
 //
-// Profiling the kernels above showed the loop is bound by instructions issued per (direction, mic) -- ~16 for
-// the strided layout (two LDS reads, address arithmetic, waits) -- not by LDS bytes.  This layout spends LDS
-// capacity to cut that to ~8 (pad) / ~15 (lerp):
-//   * every staged mic row is kept in FOUR copies shifted by 0..3 samples, so a delay p = 4q + r becomes one
-//     16-byte-ALIGNED ds_read_b128 from copy r at quad offset -q: no sub-quad alignment work, no branches;
-//   * lane l owns the four consecutive samples 4l..4l+3 (one read = all 256 samples of the row);
+//   * every staged mic row is kept in FOUR copies shifted by 0..3 samples, so a delay p = 4q + r becomes a
+//     16-byte-ALIGNED read from copy r at quad offset -q: no sub-quad alignment work, no branches;
+//   * lane l owns the four consecutive samples 4l..4l+3 of a 256-sample segment (one quad read = a whole segment row);
 //   * for lerp the staged rows also carry D[i] = s[i+1] - s[i] (rounded exactly as the reference's subtraction,
 //     D[-1] = 0), so a sample is fma(h, D[i], s[i]) -- the reference's own two roundings -- and the i < 0 guard
 //     falls out of the zero prefix;
-//   * the copies of a whole frame no longer fit in LDS, so the mics are staged in chunks of 16 (pad) / 8 (lerp)
-//     and every wave carries 4 directions' accumulators across the chunks; the next chunk's samples are already
-//     in registers (global loads issued a chunk ahead) when the buffer is rewritten;
-//   * the chunk buffer (<= 80 KiB, two workgroups per CU) doubles as the scratch for the k-ordered power sum.
+//   * the copies of a whole frame do not fit in LDS, so the mics are staged in chunks of up to 16 and every wave
+//     carries its directions' accumulators across the chunks; the next chunk's samples are already in registers
+//     (global loads issued a chunk ahead) when the buffer is rewritten;
+//   * the chunk buffer doubles as the scratch for the k-ordered power sum.
 // Mic order and operation order are unchanged, so the maps stay bit-identical to the CPU reference.
 // Digest of a `whole` table for the shifted-copies layout: entry (d, m) -> LDS byte offset of the aligned quad row that
 // direction d reads for staged mic m % mic_chunk (copy (p & 3), shifted back by p >> 2 quads; lerp reads one sample
