@@ -143,6 +143,26 @@ def test_edge_shapes_match_oracle(nat, oracle_lib, algo, case):
     assert max_rel(got, want) <= REL_TOL, (got, want)
 
 
+@pytest.mark.parametrize("algo", ["pad", "lerp", "hybrid"])
+def test_reloading_a_table_of_the_same_shape_takes_effect(nat, oracle_lib, algo):
+    """load_coefficients_* twice with different delays and unchanged sizes (a steering update): the second table must be
+    the one used (the kernels work from a digest derived from the table, which has to be rebuilt)."""
+    from interface import config
+    M, N, X, Y, T = 64, 256, 9, 7, 8
+    config.configure(N_MICROPHONES=M, N_SAMPLES=N, MAX_RES_X=X, MAX_RES_Y=Y, N_TAPS=T)
+    rng = np.random.default_rng(11)
+    sig = (rng.standard_normal((M, N)) * 0.25).astype(np.float32)
+    mics = np.arange(M, dtype=np.int32)
+    orc = oracle_lib.Oracle(N, X, Y, T)
+    for scale in (10.0, 23.0):
+        delays = rng.uniform(0, scale, size=(X, Y, M))
+        table = delays.astype(int).astype(np.int32) if algo == "pad" else np.float32(delays)
+        orc.load(ALGOS[algo], table)
+        want = orc.mimo_range(ALGOS[algo], sig, mics, 0, X * Y)
+        got = run_product(nat, algo, table, sig, mics)
+        assert max_rel(got, want) <= REL_TOL, scale
+
+
 def test_zero_signal_and_empty_contribution(nat):
     """All-zero block -> exactly zero power; every delay >= N -> exactly zero power."""
     from interface import config

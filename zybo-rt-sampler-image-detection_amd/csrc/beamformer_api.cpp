@@ -47,6 +47,17 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// Everything a digest (bf::launch_digest) depends on; compared field by field.
+struct DigestKey {
+    bool valid = false;
+    int mic_chunk = 0, row_stride = 0, lead = 0, algo = 0, dpw = 0, dir_begin = 0, dir_end = 0, n_mics = 0;
+    bool operator==(const DigestKey& o) const
+    {
+        return valid && o.valid && mic_chunk == o.mic_chunk && row_stride == o.row_stride && lead == o.lead && algo == o.algo && dpw == o.dpw &&
+               dir_begin == o.dir_begin && dir_end == o.dir_end && n_mics == o.n_mics;
+    }
+};
+
 // One loaded coefficient set (what a load_coefficients_* call leaves behind).
 struct TableSet {
     bool loaded = false;
@@ -56,8 +67,8 @@ struct TableSet {
     DevBuf<float> frac;
     DevBuf<float> taps;
     DevBuf<int32_t> digest;   // shifted-copies layout: LDS offsets per (direction, mic), see bf::launch_digest
-    long long digest_key = -1; // layout the digest was built for
-    void drop() { loaded = false; entries = 0; max_whole = 0; digest_key = -1; whole.release(); frac.release(); taps.release(); digest.release(); }
+    DigestKey digest_key;     // what the digest was built for
+    void drop() { loaded = false; entries = 0; max_whole = 0; digest_key = DigestKey{}; whole.release(); frac.release(); taps.release(); digest.release(); }
 };
 
 enum Slot { SLOT_PAD = 0, SLOT_LERP, SLOT_FIR, SLOT_HYBRID, SLOT_TRUNC, SLOT_COUNT };
@@ -282,9 +293,8 @@ bool ensure_digest(TableSet& t, bf::DasLaunch& L, const bf::DasPlan& plan, hipSt
 {
     if (plan.layout != 2 || L.algo == bf::ALGO_FIR_NAIVE || L.algo == bf::ALGO_FIR_VEC) return true;   // the plain FIRs have no whole-sample table
     // everything the digest depends on: the plan's geometry, the algorithm and (grouped layouts) the direction range
-    const long long key = ((long long)plan.mic_chunk << 40) ^ ((long long)plan.row_stride << 20) ^ ((long long)plan.lead << 4) ^ L.algo ^
-                          ((long long)plan.dpw << 52) ^ ((long long)L.dir_begin * 1000003LL) ^ ((long long)L.dir_end * 7919LL << 8);
-    if (t.digest_key != key || !t.digest.p) {
+    const DigestKey key{true, plan.mic_chunk, plan.row_stride, plan.lead, L.algo, plan.dpw, L.dir_begin, L.dir_end, L.n_mics};
+    if (!(t.digest_key == key) || !t.digest.p) {
         if (!HIP_OK(t.digest.reserve(bf::digest_elements(L, plan)))) return false;
         if (!HIP_OK(bf::launch_digest(L, plan, t.digest.p, stream))) return false;
         t.digest_key = key;
@@ -431,6 +441,7 @@ bool load_whole_only(int slot, const int* whole, int n, const char* who)
     if (!sanitize_whole(w, s.sz.n_samples, &mx, who)) return false;
     if (!upload(t.whole, w.data(), w.size())) return false;
     t.loaded = true; t.entries = n; t.max_whole = mx;
+    t.digest_key = DigestKey{};   // new table values: any digest built from the old ones is stale
     return true;
 }
 
@@ -580,6 +591,7 @@ void load_coefficients_lerp(float* delays, int n)
     if (!sanitize_whole(w, s.sz.n_samples, &mx, "load_coefficients_lerp")) return;
     if (!upload(t.whole, w.data(), w.size()) || !upload(t.frac, h.data(), h.size())) return;
     t.loaded = true; t.entries = n; t.max_whole = mx;
+    t.digest_key = DigestKey{};   // new table values: any digest built from the old ones is stale
 }
 void unload_coefficients_lerp(void) { std::lock_guard<std::mutex> lock(S().mu); S().tab[SLOT_LERP].drop(); }
 
@@ -613,6 +625,7 @@ void load_coefficients_convolve(float* h, int n)
     TableSet& t = s.tab[SLOT_FIR];
     if (!upload(t.taps, h, (size_t)n)) return;
     t.loaded = true; t.entries = n; t.max_whole = 0;
+    t.digest_key = DigestKey{};
 }
 void unload_coefficients_convolve(void) { std::lock_guard<std::mutex> lock(S().mu); S().tab[SLOT_FIR].drop(); }
 
@@ -659,6 +672,7 @@ void load_coefficients_convolve_hybrid(float* delays, int n)
     if (!sanitize_whole(w, s.sz.n_samples, &mx, "load_coefficients_convolve_hybrid")) return;
     if (!upload(t.whole, w.data(), w.size()) || !upload(t.taps, taps.data(), taps.size())) return;
     t.loaded = true; t.entries = n; t.max_whole = mx;
+    t.digest_key = DigestKey{};   // new table values: any digest built from the old ones is stale
 }
 void unload_coefficients_convolve_hybrid(void) { std::lock_guard<std::mutex> lock(S().mu); S().tab[SLOT_HYBRID].drop(); }
 
