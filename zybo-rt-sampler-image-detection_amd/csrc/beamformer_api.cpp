@@ -297,6 +297,8 @@ bool ensure_digest(TableSet& t, bf::DasLaunch& L, const bf::DasPlan& plan, hipSt
     if (!(t.digest_key == key) || !t.digest.p) {
         if (!HIP_OK(t.digest.reserve(bf::digest_elements(L, plan)))) return false;
         if (!HIP_OK(bf::launch_digest(L, plan, t.digest.p, stream))) return false;
+        // once per (table, layout): wait, so that a later launch on ANOTHER stream cannot overtake the digest's construction
+        if (!HIP_OK(hipStreamSynchronize(stream))) return false;
         t.digest_key = key;
     }
     L.tab.digest = t.digest.p;
@@ -904,6 +906,7 @@ int bf_fd_dft_device(const float* d_frames, int m_total, int frames, const int* 
     if (s.fd_tw_key != key || !s.fd_tw.p) {
         if (!HIP_OK(s.fd_tw.reserve(bf::fd_twiddle_floats(s.sz.n_samples, n_bins)))) return -1;
         if (!HIP_OK(bf::launch_fd_twiddles(s.sz.n_samples, bin_lo, n_bins, s.fd_tw.p, st))) return -1;
+        if (!HIP_OK(hipStreamSynchronize(st))) return -1;     // once per (N, bin range): see ensure_digest
         s.fd_tw_key = key;
     }
     return HIP_OK(bf::launch_fd_dft(d_frames, s.d_mics.p, m_total, s.sz.n_samples, frames, n, bin_lo, n_bins, s.fd_tw.p, d_xre_mf, d_xim_mf, d_xre_fm, d_xim_fm,
