@@ -365,3 +365,47 @@ def test_beamformer_module_surface(nat, oracle_lib):
     out = B.listen()
     assert out.tobytes() == orc.miso_pad(seen, whole, np.arange(M, dtype=np.int32), off).tobytes()
     B.disconnect()
+
+
+def test_beamformer_producer_loops(nat, oracle_lib):
+    """The remaining lib.beamformer entry points (main.pyx:554-572, 810-820): map producers with steering requests,
+    the MISO block producer, the audio hook that stands in for PortAudio."""
+    import queue as pyqueue
+    from lib import beamformer as B
+    c = util.configure("cfg1")
+    M, N, X, Y = c["M"], c["N"], c["X"], c["Y"]
+    sig = util.inputs("cfg1")["s3"]
+    mics = np.arange(M, dtype=np.int32)
+    B.connect(replay_mode=True, verbose=False)
+    B.publish(sig)
+    sig = np.empty((M, N), dtype=np.float32)
+    B.receive(sig)                      # what the loops see: the published window with the dead-microphone rows zeroed (api.c:835-858)
+    whole = util.table_for("pad", "cfg1")
+    orc = oracle_lib.Oracle(N, X, Y, c["T"])
+    want_map = orc.mimo_pad(sig, whole, mics)
+    blocks = []
+    B.audio_sink = lambda blk: blocks.append(blk.copy())
+    try:
+        q_steer, q_out = pyqueue.Queue(), pyqueue.Queue()
+        q_steer.put((0.25, 0.75))
+        B.multi_pad(q_steer, q_out, True, max_frames=2)
+        (img, _), (img2, _) = q_out.get(), q_out.get()
+        assert img.tobytes() == want_map.tobytes() and img2.tobytes() == want_map.tobytes()
+        off = int(int(0.75 * Y) * X * M + int(0.25 * X) * M)           # main.pyx:517-528
+        assert B._steer_offset == off and len(blocks) == 2
+        nat.lib.load_coefficients_pad(nat.iptr(whole.ravel()), whole.size); nat.check()
+        assert blocks[1].tobytes() == orc.miso_pad(sig, whole, mics, off).tobytes()
+        q = pyqueue.Queue()
+        B.uti_api_with_miso(q, True, max_frames=1)
+        assert q.get()[0].tobytes() == want_map.tobytes() and B._steer_offset == B.steer_cartesian_degree(0, 0)
+        q = pyqueue.Queue()
+        B.miso_api(q, True, max_frames=1)
+        assert q.get().tobytes() == orc.miso_pad(sig, whole, mics, B._steer_offset).tobytes()
+        q = pyqueue.Queue()
+        q.put((0.5, 0.5))
+        B.pure_miso_pad(q, True, max_requests=1)
+        assert B._steer_offset == int(int(0.5 * Y) * X * M + int(0.5 * X) * M)
+        B.just_miso_api(pyqueue.Queue(), True, max_frames=1)
+    finally:
+        B.audio_sink = None
+        B.disconnect()

@@ -3,7 +3,9 @@ index arithmetic and the producer loops that turn the newest frame into a power 
 
 Out of scope here (kept in the reference): the UDP receiver child process, PortAudio playback, camera / pcap capture
 and the OpenCV demo entry points.  `connect()` therefore does not fork a receiver; a frame source (replay file, test,
-or a real receiver process) hands each window over with `publish(signals)`, which is what `get_data()` returns."""
+or a real receiver process) hands each window over with `publish(signals)`, which is what `get_data()` returns.
+Where the reference's loops start audio playback (`load_miso` / `load_pa`, api.c:491-575), this module offers the steered
+block instead: set `audio_sink` to a callable and the MISO loops call it with every `listen()` block."""
 import queue
 
 import numpy as np
@@ -14,6 +16,7 @@ from .directions import active_microphones, calculate_coefficients, calculate_de
 
 _connected = False
 _steer_offset = 0
+audio_sink = None      # optional callable(float32 [N_SAMPLES]): receives the steered beam where the reference plays it
 
 
 def connect(replay_mode: bool = False, verbose=True) -> None:
@@ -148,11 +151,7 @@ def multi_lerp(q_steer, q_out, running, max_frames=None):
     """main.pyx:819-820 -> _loop_mimo_and_miso_lerp (:330-380): lerp maps out, steering requests in."""
     def step(img, m, n):
         nat.lib.lerp_mimo(nat.fptr(img), nat.iptr(m), n)
-        try:
-            x, y = q_steer.get(block=False)
-            stear_miso_beam(x, y)
-        except queue.Empty:
-            pass
+        _take_steering(q_steer, block=False)
     _produce(q_out, running, _load_lerp, step, nat.lib.unload_coefficients_lerp, max_frames)
 
 
@@ -160,3 +159,106 @@ def conv_api(q, running, max_frames=None):
     """main.pyx:560-561 -> api_convolve (:477-495)"""
     _produce(q, running, _load_convolve, lambda img, m, n: nat.lib.convolve_mimo_vectorized(nat.fptr(img), nat.iptr(m), n),
              nat.lib.unload_coefficients_convolve, max_frames)
+
+
+def multi_pad(q_steer, q_out, running, max_frames=None):
+    """main.pyx:816-817 -> _loop_mimo_and_miso_pad (:279-328): pad maps out, steering requests (x, y) in [0, 1) in."""
+    steer_cartesian_degree(0, 0)
+
+    def step(img, m, n):
+        nat.lib.pad_mimo(nat.fptr(img), nat.iptr(m), n)
+        _take_steering(q_steer, block=False)
+        _play()
+    _produce(q_out, running, _load_pad, step, nat.lib.unload_coefficients_pad, max_frames)
+
+
+def uti_api_with_miso(q, running, max_frames=None):
+    """main.pyx:557-558 -> api_with_miso (:417-446): the pad maps of uti_api while the beam listens at zero bearing."""
+    steer_cartesian_degree(0, 0)
+
+    def step(img, m, n):
+        nat.lib.pad_mimo(nat.fptr(img), nat.iptr(m), n)
+        _play()
+    _produce(q, running, _load_pad, step, nat.lib.unload_coefficients_pad, max_frames)
+
+
+def miso_api(q, running, max_frames=None):
+    """main.pyx:563-564 -> api_miso (:531-550): one steered block [N_SAMPLES] per newest frame."""
+    _load_pad()
+    n_out = 0
+    while _running(running):
+        try:
+            q.put(listen().copy(), timeout=1.0)
+        except queue.Full:
+            pass
+        except nat.BeamformerError:
+            break
+        n_out += 1
+        if max_frames is not None and n_out >= max_frames:
+            break
+
+
+def just_miso_api(q, running, max_frames=None, poll_s=0.1):
+    """main.pyx:566-567 -> just_miso (:448-475): tables loaded, beam at zero bearing, nothing queued; the reference's
+    PortAudio callback does the listening -- here `audio_sink`, if set, is fed once per poll."""
+    import time
+    _load_pad()
+    steer_cartesian_degree(0, 0)
+    n_out = 0
+    while _running(running):
+        if audio_sink is not None:
+            _play()
+        else:
+            time.sleep(poll_s)
+        n_out += 1
+        if max_frames is not None and n_out >= max_frames:
+            break
+    nat.lib.unload_coefficients_pad()
+
+
+def _pure_miso(q, running, load, unload, max_requests):
+    load()
+    steer_cartesian_degree(0, 0)
+    n_req = 0
+    while _running(running):
+        if not _take_steering(q, block=True, timeout=0.5):
+            continue
+        _play()
+        n_req += 1
+        if max_requests is not None and n_req >= max_requests:
+            break
+    unload()
+
+
+def pure_miso_pad(q, running, max_requests=None):
+    """main.pyx:810-811 -> _loop_miso_pad (:204-241): steering requests in, nothing out (audio only)."""
+    _pure_miso(q, running, _load_pad, nat.lib.unload_coefficients_pad, max_requests)
+
+
+def pure_miso_lerp(q, running, max_requests=None):
+    """main.pyx:813-814 -> _loop_miso_lerp (:243-277)"""
+    _pure_miso(q, running, _load_lerp, nat.lib.unload_coefficients_lerp, max_requests)
+
+
+def just_miso_loop(q, running):
+    """main.pyx:572-580: idle until `running` clears."""
+    import time
+    while _running(running):
+        time.sleep(0.1)
+
+
+def _take_steering(q, block, timeout=None):
+    """One (x, y) request off a steering queue -> stear_miso_beam; False when none was waiting."""
+    try:
+        x, y = q.get(block=block, timeout=timeout)
+    except queue.Empty:
+        return False
+    if hasattr(q, "task_done"):
+        q.task_done()
+    stear_miso_beam(x, y)
+    return True
+
+
+def _play():
+    if audio_sink is not None:
+        audio_sink(listen())
