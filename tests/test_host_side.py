@@ -119,3 +119,21 @@ def test_fails_loudly_without_gpu(native):
     native.lib.mimo_pad(native.fptr(sig), native.fptr(img), native.iptr(mics), 64)
     assert np.isnan(img).all()
     native.lib.bf_clear_error()
+
+
+def test_legacy_direction_helpers_match_the_reference(native):
+    """lib.directions.calculate_delays_ / calculate_delay_miso (directions.pyx:126-187) against vectors produced by the
+    real reference (oracle/gen_golden_legacy.py), bit for bit; plus the pass-through constants of interface.config."""
+    import hashlib
+    from interface import config
+    from lib import directions as D
+    util.configure("shipped")
+    g = np.load(os.path.join(util.GOLDEN, "legacy_directions.npz"))
+    d = D.calculate_delays_()
+    assert d.dtype == np.float32 and tuple(d.shape) == tuple(g["delays_shape"])
+    assert np.array_equal(d[::8, ::5, :], g["delays_sample"])
+    assert hashlib.sha256(np.ascontiguousarray(d).tobytes()).hexdigest() == str(g["delays_sha256"])
+    for (az, el), want in zip(g["angles"], g["miso"]):
+        assert np.array_equal(D.calculate_delay_miso(float(az), float(el)), want)
+    assert config.MAX_ANGLE == 70.0 and abs(config.ASPECT_RATIO - 4 / 3) < 1e-15 and config.WINDOW_SIZE == (720, 480)
+    util.configure("cfg1")

@@ -25,6 +25,34 @@ SKIP_N_MICS = 1
 PROPAGATION_SPEED = 340.0
 ACTIVE_TILES = 4          # `_ACTIVE_MICS` of PC/src/directions.pyx:16 (hard-coded there)
 fs = 48828                # PC/src/config.json:47 (python section)
+# The rest of the reference's generated constants (PC/src/config.json "general" / "python"): not used by the beamforming
+# path, carried so that `from interface.config import ...` lines of the reference's scripts resolve.
+EVERY_N_SAMPLES = 1
+MAX_RES = 20
+MAX_ANGLE = 70.0
+UDP_PORT = 21844
+ARRAY_SEPARATION = 0.0
+ACTIVE_ARRAYS = 3
+APPLICATION_WINDOW_WIDTH = 720
+APPLICATION_WINDOW_HEIGHT = 480
+CAMERA_SOURCE = 2
+FLIP_IMAGE = True
+APPLICATION_NAME = "BEEEEEAAAAAAM FOOOOOOORMING"
+UDP_IP = "10.0.0.1"
+UDP_REPLAY_IP = "127.0.0.1"
+FPGA_PROTOCOL_VERSION = 2
+ASPECT_RATIO = 4 / 3
+USE_COMPUTER_VISION = True
+azimuth = 0.0
+elevation = 0.0
+columns = 8
+rows = 8
+distance = 0.02
+propagation_speed = 340.0
+TIMEOUT = 30
+mode = 1
+modes = 7
+WINDOW_SIZE = (720, 480)
 
 _SIZE_KEYS = ("N_MICROPHONES", "N_SAMPLES", "N_TAPS", "MAX_RES_X", "MAX_RES_Y", "COLUMNS", "ROWS", "SKIP_N_MICS", "ACTIVE_TILES")
 _FLOAT_KEYS = ("Z", "VIEW_ANGLE", "SAMPLE_RATE", "ELEMENT_DISTANCE", "PROPAGATION_SPEED")
@@ -40,6 +68,9 @@ def _load(path):
     for k in _FLOAT_KEYS:
         if k in general:
             g[k] = float(general[k])
+    for k, v in general.items():            # pass-through constants (no expressions are evaluated)
+        if k not in _SIZE_KEYS and k not in _FLOAT_KEYS and k != "expression" and k in g and not k.startswith("_"):
+            g[k] = v
     g["BUFFER_LENGTH"] = g["N_SAMPLES"] * g["N_MICROPHONES"]
 
 

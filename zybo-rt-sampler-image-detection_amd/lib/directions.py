@@ -82,3 +82,46 @@ def calculate_coefficients():
     frac = np.ascontiguousarray(frac)
     nat.lib.bf_get_h_batch(nat.dptr(frac), frac.size, nat.fptr(h))
     return whole, h
+
+
+def _tile_factors():
+    """Element coordinates of ONE 8x8 tile about its centre, as directions.pyx:143-147 / :174-177 compute them
+    (distance 0.02 hard-coded there): float64 [ROWS*COLUMNS] column and row offsets, row-major."""
+    distance = 0.02
+    half = distance / 2.0
+    col = np.arange(config.COLUMNS) * distance - config.COLUMNS * half + half
+    row = np.arange(config.ROWS) * distance - config.ROWS * half + half
+    return np.tile(col, config.ROWS), np.repeat(row, config.COLUMNS)
+
+
+def _samples_per_metre():
+    # SAMPLE_RATE and PROPAGATION_SPEED are C floats in the reference (config.pxd:14-23): a float32 division
+    return float(np.float32(config.SAMPLE_RATE) / np.float32(config.PROPAGATION_SPEED))
+
+
+def calculate_delays_():
+    """directions.pyx:126-157 (legacy, angle grid): float32 [MAX_RES_X, MAX_RES_Y, COLUMNS*ROWS*ACTIVE_TILES]; only the
+    first tile's entries are filled there, the minimum over them (or 0) is subtracted from every entry."""
+    tc, tr = _tile_factors()
+    n = config.COLUMNS * config.ROWS
+    out = np.zeros((config.MAX_RES_X, config.MAX_RES_Y, n * config.ACTIVE_TILES), dtype=np.float32)
+    xf = np.sin(np.linspace(-config.MAX_ANGLE, config.MAX_ANGLE, config.MAX_RES_X) * -np.pi / 180.0)
+    yf = np.sin(np.linspace(-config.MAX_ANGLE, config.MAX_ANGLE, config.MAX_RES_Y) * -np.pi / 180.0)
+    d = tc[None, None, :] * xf[:, None, None] + tr[None, None, :] * yf[None, :, None]          # float64
+    smallest = np.minimum(d.min(axis=2), 0.0)
+    out[:, :, :n] = d                                                                             # rounded to float32 on store
+    out -= smallest[:, :, None]                                                                   # float32 arithmetic, as in-place ops on the array
+    out *= _samples_per_metre()
+    return out
+
+
+def calculate_delay_miso(azimuth, elevation):
+    """directions.pyx:159-187 (legacy): whole-sample delays of one (azimuth, elevation) in degrees, int array."""
+    tc, tr = _tile_factors()
+    n = config.COLUMNS * config.ROWS
+    out = np.zeros(n * config.ACTIVE_TILES, dtype=np.float32)
+    d = tc * np.sin(azimuth * -np.pi / 180.0) + tr * np.sin(elevation * -np.pi / 180.0)
+    out[:n] = d
+    out -= min(float(d.min()), 0.0)
+    out *= _samples_per_metre()
+    return out.astype(int)
