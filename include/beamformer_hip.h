@@ -131,6 +131,9 @@ int bf_das_device(int algo, const float *d_signals, int m_total, float *d_images
 int bf_ingest(const void *packets, int n_arrays, int rows, int columns, float *frame);
 int bf_ingest_device(const void *d_packets, int n_arrays, int rows, int columns, float *d_frame, void *stream);
 
+/* bf_jet_lut: visual.py:26-49 generate_color_map("jet") -- the colour table the colourise kernel uses, uint8 [256][3]. */
+void bf_jet_lut(unsigned char *out768);
+
 /* ---- heat-map post-processing on the device (PC/src/visual.py; display side of the path) ----
  * bf_heatmap_colorize_device: visual.py:143-185 -- d_power float32 [frames][MAX_RES_X*MAX_RES_Y] -> d_small uint8
  *   [frames][MAX_RES_Y][MAX_RES_X][3] (reversed-jet colours, flipped as the reference indexes it) and should_overlay flags.

@@ -137,3 +137,14 @@ def test_legacy_direction_helpers_match_the_reference(native):
         assert np.array_equal(D.calculate_delay_miso(float(az), float(el)), want)
     assert config.MAX_ANGLE == 70.0 and abs(config.ASPECT_RATIO - 4 / 3) < 1e-15 and config.WINDOW_SIZE == (720, 480)
     util.configure("cfg1")
+
+
+def test_visual_host_helpers(native):
+    """visual.generate_color_map / local_max (PC/src/visual.py:26-63): the colour table equals the matplotlib-derived
+    fixture the colourise kernel is tested against; local_max marks >=-neighbour peaks above the threshold."""
+    import visual
+    assert np.array_equal(visual.generate_color_map(), np.load(os.path.join(util.GOLDEN, "jet_lut.npy")))
+    img = np.array([[0, 1, 0, 0], [1, 5, 1, 0], [0, 1, 6.0, 0.4]])
+    want = np.zeros_like(img, dtype=bool)
+    want[1, 1] = want[2, 2] = True
+    assert np.array_equal(visual.local_max(img, 0.5), want)

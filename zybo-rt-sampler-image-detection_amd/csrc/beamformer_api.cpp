@@ -946,6 +946,17 @@ int bf_fd_mvdr_power_device(const float* d_lire_t, const float* d_liim_t, const 
     return HIP_OK(bf::launch_fd_mvdr_power(d_lire_t, d_liim_t, d_are, d_aim, n_mics, n_dirs, n_bins, d_power, s.fd_work.p, s.fd_work.cap, st)) ? 0 : -1;
 }
 
+// The 256-entry colour table of the colourise kernel (visual.py:26-49 generate_color_map("jet")), uint8 [256][3].
+void bf_jet_lut(unsigned char* out768)
+{
+    struct Rgb { unsigned char r, g, b; };
+    static const Rgb kJet[256] = {
+#include "jet_lut.inc"
+    };
+    if (!out768) return;
+    for (int i = 0; i < 256; ++i) { out768[3 * i] = kJet[i].r; out768[3 * i + 1] = kJet[i].g; out768[3 * i + 2] = kJet[i].b; }
+}
+
 // ---------------------------------------------------------------- detector post-processing
 
 int bf_yolo_decode_device(const void* const raw[3], const int h[3], const int w[3], const int strides[3], const float* anchors, int batch, int nc,
