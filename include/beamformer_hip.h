@@ -159,7 +159,7 @@ int bf_power_center_device(const float *d_power, int frames, float *d_centers, f
  *   bf_fd_dft_device        rfft of every active mic row of every frame -> X as [K][M][F] and as [K][F][M]
  *   bf_fd_das_power_device  P[f][d] = sum_k | sum_m X[k][m][f] a[k][m][d] |^2                                    -> float32 [F][D]
  *   bf_fd_covariance_device R[k] = (1/F) sum_f x x^H                                                              -> [K][M][M]
- *   bf_fd_cholesky_inverse_device  R += loading*tr(R)/M*I = L L^H;  writes inverse(L) transposed [K][col][row];  M <= 128;
+ *   bf_fd_cholesky_inverse_device  R += loading*tr(R)/M*I = L L^H;  writes inverse(L) transposed [K][col][row];  M <= 256 (two blocks of 128 above 128);
  *                           d_status int32 [K] (zeroed by the caller) receives j+1 where a pivot was not positive
  *   bf_fd_mvdr_power_device P[d] = sum_k 1 / || inverse(L_k) a[k][:, d] ||^2                                     -> float32 [D]  */
 int bf_fd_steering_device(const double *d_tau, const double *d_freq, int n_dirs, int n_mics, int n_bins, float *d_are, float *d_aim, void *stream);

@@ -138,3 +138,52 @@ def test_gpu_mvdr_quadratic_form_matches_numpy(native, M, J, B):
     y = np.einsum("bki,bkj->bij", l.astype(np.complex128), np.conj(a.astype(np.complex128)))
     want = (1.0 / (np.abs(y) ** 2).sum(1)).sum(0)
     assert np.max(np.abs(q.double().cpu().numpy() - want) / want) <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,B", [(192, 3), (256, 4), (129, 2)])
+def test_gpu_blocked_cholesky_inverse_matches_numpy(native, M, B):
+    """bf_fd_cholesky_inverse_device above 128 mics (two blocks of 128 + strided GEMMs): the transposed planes must be
+    inverse(cholesky(R + loading tr(R)/M I)) of random Hermitian positive-definite matrices."""
+    import torch
+    rng = np.random.default_rng(M)
+    x = rng.standard_normal((B, M, 2 * M)) + 1j * rng.standard_normal((B, M, 2 * M))
+    r = (x @ x.conj().transpose(0, 2, 1)) / (2 * M)
+    loading = 1e-2
+    dev = lambda v: torch.from_numpy(np.ascontiguousarray(v.astype(np.float32))).cuda()
+    rr, ri = dev(r.real), dev(r.imag)
+    lr = torch.full((B, M, M), float("nan"), dtype=torch.float32, device="cuda")
+    li = torch.full((B, M, M), float("nan"), dtype=torch.float32, device="cuda")
+    st = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    assert native.lib.bf_fd_cholesky_inverse_device(rr.data_ptr(), ri.data_ptr(), M, B, loading, lr.data_ptr(), li.data_ptr(), st.data_ptr(), None) == 0, native.check()
+    assert int(st.abs().max().item()) == 0
+    got_t = lr.double().cpu().numpy() + 1j * li.double().cpu().numpy()          # [b][c][r] = Linv[r][c]
+    r32 = rr.double().cpu().numpy() + 1j * ri.double().cpu().numpy()
+    for b in range(B):
+        rl = r32[b] + loading * np.trace(r32[b]).real / M * np.eye(M)
+        want = np.linalg.inv(np.linalg.cholesky(rl))
+        got = got_t[b].T
+        assert np.max(np.abs(got - want)) <= 2e-4 * np.max(np.abs(want)), (M, b)
+        assert np.max(np.abs(np.triu(got, 1))) == 0.0
+
+
+@pytest.mark.gpu
+def test_gpu_mvdr_256_mics_matches_float64_oracle(native):
+    """BASELINE config 5's array (4 tiles = 256 mics) through the whole MVDR path against the float64 oracle."""
+    import torch
+    import freq_np as F
+    from realtime_scripts import beam_forming_algorithm as B, config as C
+    old = (C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y)
+    C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y = 256, 4, 9, 7
+    try:
+        fb = B.FrequencyBeamformer()
+        assert fb.M == 256
+        t = F.tables(res_x=9, res_y=7, arrays=4)
+        frames = _scene(t, 6, 2, 320, np.random.default_rng(9), M=256).astype(np.float32)
+        want = F.mvdr_power(frames.astype(np.float64), t["phase_shift"], t["bin_lo"], t["bin_hi"], loading=1e-2).ravel()
+        d_frames = torch.from_numpy(np.ascontiguousarray(frames.transpose(0, 2, 1))).cuda()      # [F, M, N] mic-major
+        got = fb.mvdr_power(d_frames, loading=1e-2).double().cpu().numpy()
+        assert np.argmax(got) == np.argmax(want) == 6 * 7 + 2
+        assert np.max(np.abs(got - want) / want) <= 5e-4          # conditioning of R^-1 in float32 at 256 mics
+    finally:
+        C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y = old

@@ -87,6 +87,7 @@ struct State {
     DevBuf<float> d_frame, d_image, d_out, d_init, d_one_taps, d_one_frac;
     DevBuf<int32_t> d_mics, d_one_whole;
     DevBuf<float> fd_work;               // partial planes of the bin-reducing GEMMs (bf::fd_workspace_floats)
+    DevBuf<float> fd_chol_work;          // blocks of the 129..256-mic Cholesky / inverse (bf::fd_cholesky_workspace_floats)
     DevBuf<float> fd_tw;                 // twiddles of the MFMA DFT for (N, bin_lo, n_bins) = fd_tw_key
     long long fd_tw_key = -1;
     std::vector<int> mics_host;          // what d_mics currently holds
@@ -932,15 +933,18 @@ int bf_fd_cholesky_inverse_device(const float* d_rre, const float* d_rim, int n_
                                   int* d_status, void* stream)
 {
     FD_ENTER(d_rre && d_rim && d_lire_t && d_liim_t && d_status && n_mics > 0 && n_bins > 0, "bf_fd_cholesky_inverse_device")
-    if (n_mics > 128) { set_error("bf_fd_cholesky_inverse_device: %d mics; the in-LDS factorisation handles at most 128", n_mics); return -1; }
-    return HIP_OK(bf::launch_fd_cholesky_inverse(d_rre, d_rim, n_mics, n_bins, loading, d_lire_t, d_liim_t, d_status, st)) ? 0 : -1;
+    if (n_mics > 256) { set_error("bf_fd_cholesky_inverse_device: %d mics; the blocked factorisation handles at most 256", n_mics); return -1; }
+    const size_t work = bf::fd_cholesky_workspace_floats(n_mics, n_bins);
+    if (work && !HIP_OK(s.fd_chol_work.reserve(work))) return -1;
+    return HIP_OK(bf::launch_fd_cholesky_inverse(d_rre, d_rim, n_mics, n_bins, loading, d_lire_t, d_liim_t, d_status, s.fd_chol_work.p, s.fd_chol_work.cap, st))
+               ? 0 : -1;
 }
 
 int bf_fd_mvdr_power_device(const float* d_lire_t, const float* d_liim_t, const float* d_are, const float* d_aim, int n_mics, int n_dirs, int n_bins,
                             float* d_power, void* stream)
 {
     FD_ENTER(d_lire_t && d_liim_t && d_are && d_aim && d_power && n_mics > 0 && n_dirs > 0 && n_bins > 0, "bf_fd_mvdr_power_device")
-    if (n_mics > 128) { set_error("bf_fd_mvdr_power_device: %d mics; at most 128", n_mics); return -1; }
+    if (n_mics > 256) { set_error("bf_fd_mvdr_power_device: %d mics; at most 256", n_mics); return -1; }
     const size_t work = bf::fd_workspace_floats(1, n_dirs, n_bins);
     if (!HIP_OK(s.fd_work.reserve(work))) return -1;
     return HIP_OK(bf::launch_fd_mvdr_power(d_lire_t, d_liim_t, d_are, d_aim, n_mics, n_dirs, n_bins, d_power, s.fd_work.p, s.fd_work.cap, st)) ? 0 : -1;

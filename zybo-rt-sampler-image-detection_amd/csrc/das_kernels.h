@@ -107,8 +107,11 @@ size_t fd_workspace_floats(int n_rows, int n_dirs, int n_bins);
 hipError_t launch_fd_das_power(const float* xre_mf, const float* xim_mf, const float* are, const float* aim, int n_frames, int n_mics, int n_dirs,
                                int n_bins, float* d_power, float* d_work, size_t work_floats, hipStream_t stream);
 hipError_t launch_fd_covariance(const float* xre_fm, const float* xim_fm, int n_frames, int n_mics, int n_bins, float* rre, float* rim, hipStream_t stream);
+// Up to 128 mics: one in-LDS factorisation per bin, no workspace.  129..256 mics: two-by-two blocks of 128 (in-LDS kernel on
+// the diagonal blocks, small strided MFMA GEMMs in between), needs fd_cholesky_workspace_floats(n_mics, n_bins) floats.
+size_t fd_cholesky_workspace_floats(int n_mics, int n_bins);
 hipError_t launch_fd_cholesky_inverse(const float* rre, const float* rim, int n_mics, int n_bins, float loading, float* lire_t, float* liim_t,
-                                      int* d_status, hipStream_t stream);
+                                      int* d_status, float* d_work, size_t work_floats, hipStream_t stream);
 hipError_t launch_fd_mvdr_power(const float* lire_t, const float* liim_t, const float* are, const float* aim, int n_mics, int n_dirs, int n_bins,
                                 float* d_power, float* d_work, size_t work_floats, hipStream_t stream);
 

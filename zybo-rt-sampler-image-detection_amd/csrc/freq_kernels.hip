@@ -415,8 +415,14 @@ __global__ void __launch_bounds__(256) steering_kernel(const double* __restrict_
 //     updated with a_ij conj(a_cj) / d_j, and all columns are scaled by 1 / sqrt(d_j) afterwards;
 //   * inverse: column c of L^-1 by forward substitution, 4 lanes per column splitting the dot product, written into the
 //     (free) upper triangle at the transposed position, which is exactly the output layout.
-__global__ void __launch_bounds__(256) cholesky_inverse_kernel(const float* __restrict__ rre, const float* __restrict__ rim, int M, float loading,
-                                                               float* __restrict__ lire_t, float* __restrict__ liim_t, int* __restrict__ status)
+// Generalised for the blocked factorisation of larger matrices: the M x M input block sits in a matrix of leading
+// dimension ld_in (one matrix of in_stride floats per bin), the transposed inverse goes to a block of leading dimension
+// ld_out, and the diagonal loading is either relative to this block's trace (load_abs == nullptr) or an absolute per-bin
+// value computed from the whole matrix.  `status_base` offsets the column index reported for a non-positive pivot.
+__global__ void __launch_bounds__(256) cholesky_inverse_kernel(const float* __restrict__ rre, const float* __restrict__ rim, size_t in_stride, int ld_in, int M,
+                                                               float loading, const float* __restrict__ load_abs, float* __restrict__ lire_t,
+                                                               float* __restrict__ liim_t, size_t out_stride, int ld_out, int* __restrict__ status,
+                                                               int status_base)
 {
     extern __shared__ float sm[];
     const int LD = M + 1;
@@ -425,27 +431,27 @@ __global__ void __launch_bounds__(256) cholesky_inverse_kernel(const float* __re
     __shared__ float s_trace;
     __shared__ float rdiag[128];    // 1 / L[i][i]
     const int b = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
-    const float* Rr = rre + (size_t)b * M * M;
-    const float* Ri = rim + (size_t)b * M * M;
+    const float* Rr = rre + (size_t)b * in_stride;
+    const float* Ri = rim + (size_t)b * in_stride;
     for (int i = t; i < M * M; i += nt) {
         const int r = i / M, c = i - r * M;
-        Lr[r * LD + c] = Rr[i];
-        Li[r * LD + c] = Ri[i];
+        Lr[r * LD + c] = Rr[(size_t)r * ld_in + c];
+        Li[r * LD + c] = Ri[(size_t)r * ld_in + c];
     }
     __syncthreads();
     if (t == 0) {
         float tr = 0.0f;
         for (int i = 0; i < M; ++i) tr += Lr[i * LD + i];
-        s_trace = tr / (float)M;
+        s_trace = load_abs ? load_abs[b] : loading * (tr / (float)M);
     }
     __syncthreads();
-    if (t < M) { Lr[t * LD + t] += loading * s_trace; Li[t * LD + t] = 0.0f; }
+    if (t < M) { Lr[t * LD + t] += s_trace; Li[t * LD + t] = 0.0f; }
 
     const int ti = t >> 4, tc = t & 15;
     for (int j = 0; j < M; ++j) {
         __syncthreads();                       // column j and d_j are final
         const float d = Lr[j * LD + j];
-        if (t == 0 && !(d > 0.0f)) status[b] = j + 1;
+        if (t == 0 && !(d > 0.0f)) status[b] = status_base + j + 1;
         const float invd = 1.0f / fmaxf(d, 1e-30f);
         // trailing update: A[i][c] -= a_ij conj(a_cj) / d_j,  j < c <= i
         for (int i = j + 1 + ti; i < M; i += 16) {
@@ -484,12 +490,79 @@ __global__ void __launch_bounds__(256) cholesky_inverse_kernel(const float* __re
         }
     }
     __syncthreads();
-    float* Or = lire_t + (size_t)b * M * M;
-    float* Oi = liim_t + (size_t)b * M * M;
+    float* Or = lire_t + (size_t)b * out_stride;
+    float* Oi = liim_t + (size_t)b * out_stride;
     for (int e = t; e < M * M; e += nt) {       // transposed planes: [c][i] = Linv[i][c]
         const int c = e / M, i = e - c * M;
-        Or[e] = i < c ? 0.0f : (i == c ? rdiag[c] : Lr[c * LD + i]);
-        Oi[e] = i <= c ? 0.0f : Li[c * LD + i];
+        Or[(size_t)c * ld_out + i] = i < c ? 0.0f : (i == c ? rdiag[c] : Lr[c * LD + i]);
+        Oi[(size_t)c * ld_out + i] = i <= c ? 0.0f : Li[c * LD + i];
+    }
+}
+
+// ---- pieces of the blocked factorisation for 128 < M <= 256 (launch_fd_cholesky_inverse) -------------------------------
+// load[b] = loading * tr(R_b) / M over the whole matrix
+__global__ void __launch_bounds__(64) diag_load_kernel(const float* __restrict__ rre, int M, float loading, float* __restrict__ load)
+{
+    const float* R = rre + (size_t)blockIdx.x * M * M;
+    float tr = 0.0f;
+    for (int i = threadIdx.x; i < M; i += 64) tr += R[(size_t)i * M + i];
+    for (int off = 32; off > 0; off >>= 1) tr += __shfl_xor(tr, off, 64);
+    if (threadIdx.x == 0) load[blockIdx.x] = loading * (tr / (float)M);
+}
+
+// Small batched complex GEMM with arbitrary element strides (so that transposes and sub-blocks need no copies):
+//   C(i, j) = alpha * sum_k opA(A(k, i)) opB(B(k, j)) + beta * Cin(i, j),   op = conj or identity.
+// One wave per 32 x 32 tile, exact-f32 MFMA as everywhere in this file.  Sizes here are <= 128^3 per bin: not tuned.
+struct StridedGemm {
+    const float *a_re, *a_im; size_t a_batch; int a_sk, a_si;
+    const float *b_re, *b_im; size_t b_batch; int b_sk, b_sj;
+    const float *cin_re, *cin_im; size_t cin_batch; int cin_si, cin_sj;
+    float *c_re, *c_im; size_t c_batch; int c_si, c_sj;
+    int I, J, K, conj_a, conj_b;
+    float alpha, beta;
+};
+
+__global__ void __launch_bounds__(64) cgemm_strided_kernel(StridedGemm g)
+{
+    const int lane = threadIdx.x, li = lane & 31, lk = lane >> 5;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32, b = blockIdx.z;
+    const bool ai_ok = i0 + li < g.I, bj_ok = j0 + li < g.J;
+    const float* are = g.a_re + (size_t)b * g.a_batch + (size_t)(i0 + li) * g.a_si;
+    const float* aim = g.a_im + (size_t)b * g.a_batch + (size_t)(i0 + li) * g.a_si;
+    const float* bre = g.b_re + (size_t)b * g.b_batch + (size_t)(j0 + li) * g.b_sj;
+    const float* bim = g.b_im + (size_t)b * g.b_batch + (size_t)(j0 + li) * g.b_sj;
+    f32x16 cre, cim;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { cre[r] = 0.0f; cim[r] = 0.0f; }
+    for (int k = 0; k < g.K; k += 2) {
+        const int kk = k + lk;
+        const bool k_ok = kk < g.K;
+        const float xr = (ai_ok && k_ok) ? are[(size_t)kk * g.a_sk] : 0.0f;
+        float xi = (ai_ok && k_ok) ? aim[(size_t)kk * g.a_sk] : 0.0f;
+        const float yr = (bj_ok && k_ok) ? bre[(size_t)kk * g.b_sk] : 0.0f;
+        float yi = (bj_ok && k_ok) ? bim[(size_t)kk * g.b_sk] : 0.0f;
+        if (g.conj_a) xi = -xi;
+        if (g.conj_b) yi = -yi;
+        cre = __builtin_amdgcn_mfma_f32_32x32x2f32(xr, yr, cre, 0, 0, 0);
+        cre = __builtin_amdgcn_mfma_f32_32x32x2f32(-xi, yi, cre, 0, 0, 0);
+        cim = __builtin_amdgcn_mfma_f32_32x32x2f32(xr, yi, cim, 0, 0, 0);
+        cim = __builtin_amdgcn_mfma_f32_32x32x2f32(xi, yr, cim, 0, 0, 0);
+    }
+    const int col = j0 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = i0 + acc_row(r, lane);
+        if (row < g.I && col < g.J) {
+            float vr = g.alpha * cre[r], vi = g.alpha * cim[r];
+            if (g.cin_re) {
+                const size_t ci = (size_t)b * g.cin_batch + (size_t)row * g.cin_si + (size_t)col * g.cin_sj;
+                vr += g.beta * g.cin_re[ci];
+                vi += g.beta * g.cin_im[ci];
+            }
+            const size_t co = (size_t)b * g.c_batch + (size_t)row * g.c_si + (size_t)col * g.c_sj;
+            g.c_re[co] = vr;
+            g.c_im[co] = vi;
+        }
     }
 }
 
@@ -612,14 +685,75 @@ hipError_t launch_fd_covariance(const float* xre_fm, const float* xim_fm, int n_
     return run_gemm<EPI_STORE>(g, stream);
 }
 
-hipError_t launch_fd_cholesky_inverse(const float* rre, const float* rim, int n_mics, int n_bins, float loading, float* lire_t, float* liim_t,
-                                      int* d_status, hipStream_t stream)
+namespace {
+hipError_t run_strided(const StridedGemm& g, int batch, hipStream_t stream)
 {
-    const size_t lds = (size_t)2 * n_mics * (n_mics + 1) * sizeof(float);
+    hipLaunchKernelGGL(cgemm_strided_kernel, dim3((unsigned)((g.J + 31) / 32), (unsigned)((g.I + 31) / 32), (unsigned)batch), dim3(64), 0, stream, g);
+    return hipGetLastError();
+}
+
+hipError_t run_cholesky(const float* rre, const float* rim, size_t in_stride, int ld_in, int m, float loading, const float* load_abs, float* ore, float* oim,
+                        size_t out_stride, int ld_out, int* d_status, int status_base, int n_bins, hipStream_t stream)
+{
+    const size_t lds = (size_t)2 * m * (m + 1) * sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cholesky_inverse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(cholesky_inverse_kernel, dim3((unsigned)n_bins), dim3(256), lds, stream, rre, rim, n_mics, loading, lire_t, liim_t, d_status);
+    hipLaunchKernelGGL(cholesky_inverse_kernel, dim3((unsigned)n_bins), dim3(256), lds, stream, rre, rim, in_stride, ld_in, m, loading, load_abs, ore, oim,
+                       out_stride, ld_out, d_status, status_base);
     return hipGetLastError();
+}
+}  // namespace
+
+size_t fd_cholesky_workspace_floats(int n_mics, int n_bins)
+{
+    if (n_mics <= 128) return 0;
+    const size_t h = 128, m2 = (size_t)n_mics - h;
+    // per bin: the absolute loading, then (re, im) of L21 [m2 x h], S [m2 x m2], T [m2 x h]
+    return (size_t)n_bins * (1 + 2 * (m2 * h + m2 * m2 + m2 * h));
+}
+
+hipError_t launch_fd_cholesky_inverse(const float* rre, const float* rim, int n_mics, int n_bins, float loading, float* lire_t, float* liim_t,
+                                      int* d_status, float* d_work, size_t work_floats, hipStream_t stream)
+{
+    const int M = n_mics;
+    const size_t mm = (size_t)M * M;
+    if (M <= 128) return run_cholesky(rre, rim, mm, M, M, loading, nullptr, lire_t, liim_t, mm, M, d_status, 0, n_bins, stream);
+    if (M > 256 || d_work == nullptr || work_floats < fd_cholesky_workspace_floats(M, n_bins)) return hipErrorInvalidValue;
+
+    // Two-by-two blocks, h = 128:   R = [R11 R21^H; R21 R22],  L = [L11 0; L21 L22],  L^-1 = [X11 0; X21 X22]
+    //   X11 = L11^-1 (in-LDS kernel on R11);  L21 = R21 X11^H;  S = R22 - L21 L21^H;  X22 = chol-inverse(S);
+    //   X21 = -X22 (L21 X11).            Output planes hold the TRANSPOSE: out[c][r] = L^-1[r][c].
+    const int h = 128, m2 = M - h;
+    float* load = d_work;
+    float* l21_re = load + n_bins;                       float* l21_im = l21_re + (size_t)n_bins * m2 * h;
+    float* s_re = l21_im + (size_t)n_bins * m2 * h;      float* s_im = s_re + (size_t)n_bins * m2 * m2;
+    float* t_re = s_im + (size_t)n_bins * m2 * m2;       float* t_im = t_re + (size_t)n_bins * m2 * h;
+    hipError_t e = hipMemsetAsync(lire_t, 0, (size_t)n_bins * mm * sizeof(float), stream);          // the upper-right block of L^-1 is zero
+    if (e == hipSuccess) e = hipMemsetAsync(liim_t, 0, (size_t)n_bins * mm * sizeof(float), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(diag_load_kernel, dim3((unsigned)n_bins), dim3(64), 0, stream, rre, M, loading, load);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    // X11^T -> out[c][r], c, r < h
+    if ((e = run_cholesky(rre, rim, mm, M, h, 0.0f, load, lire_t, liim_t, mm, M, d_status, 0, n_bins, stream)) != hipSuccess) return e;
+    // L21(i, j) = sum_k R21(i, k) conj(X11(j, k)):  A(k, i) = R[(h + i) M + k],  B(k, j) = X11(j, k) = out[k M + j]
+    StridedGemm g1{rre + (size_t)h * M, rim + (size_t)h * M, mm, 1, M,   lire_t, liim_t, mm, M, 1,   nullptr, nullptr, 0, 0, 0,
+                   l21_re, l21_im, (size_t)m2 * h, h, 1,   m2, h, h, 0, 1, 1.0f, 0.0f};
+    if ((e = run_strided(g1, n_bins, stream)) != hipSuccess) return e;
+    // S(i, j) = R22(i, j) - sum_k L21(i, k) conj(L21(j, k))
+    StridedGemm g2{l21_re, l21_im, (size_t)m2 * h, 1, h,   l21_re, l21_im, (size_t)m2 * h, 1, h,   rre + (size_t)h * M + h, rim + (size_t)h * M + h, mm, M, 1,
+                   s_re, s_im, (size_t)m2 * m2, m2, 1,   m2, m2, h, 0, 1, -1.0f, 1.0f};
+    if ((e = run_strided(g2, n_bins, stream)) != hipSuccess) return e;
+    // X22^T -> out[h + c][h + r]
+    if ((e = run_cholesky(s_re, s_im, (size_t)m2 * m2, m2, m2, 0.0f, load, lire_t + (size_t)h * M + h, liim_t + (size_t)h * M + h, mm, M, d_status, h, n_bins,
+                          stream)) != hipSuccess) return e;
+    // T(i, j) = sum_k L21(i, k) X11(k, j):  B(k, j) = X11(k, j) = out[j M + k]
+    StridedGemm g3{l21_re, l21_im, (size_t)m2 * h, 1, h,   lire_t, liim_t, mm, 1, M,   nullptr, nullptr, 0, 0, 0,
+                   t_re, t_im, (size_t)m2 * h, h, 1,   m2, h, h, 0, 0, 1.0f, 0.0f};
+    if ((e = run_strided(g3, n_bins, stream)) != hipSuccess) return e;
+    // X21(i, j) = -sum_k X22(i, k) T(k, j), stored transposed at out[j M + h + i]:  A(k, i) = X22(i, k) = out[(h + k) M + h + i]
+    StridedGemm g4{lire_t + (size_t)h * M + h, liim_t + (size_t)h * M + h, mm, M, 1,   t_re, t_im, (size_t)m2 * h, h, 1,   nullptr, nullptr, 0, 0, 0,
+                   lire_t + h, liim_t + h, mm, 1, M,   m2, h, m2, 0, 0, -1.0f, 0.0f};
+    return run_strided(g4, n_bins, stream);
 }
 
 hipError_t launch_fd_mvdr_power(const float* lire_t, const float* liim_t, const float* are, const float* aim, int n_mics, int n_dirs, int n_bins,
