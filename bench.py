@@ -155,6 +155,14 @@ def extras(torch, nat, delays, mics, dev):
                        "mfma_tflops": flop / dt / 1e12, "mfma_peak_tflops_f32": 157.3}
         dt = timed(lambda: fb.das_power(frames), torch, 5)
         out["freq_domain_das"] = {"frames_per_s": F / dt, "ms_per_step": dt * 1e3, "mfma_tflops": fb.K * 8.0 * M * F * fb.D / dt / 1e12}
+        # BASELINE config 5's array: 4 tiles = 256 mics (two-block Cholesky), the as-shipped 57 x 32 grid, 320 windows per map
+        C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y = 256, 4, 57, 32
+        fb4 = B.FrequencyBeamformer()
+        F4 = 320
+        frames4 = torch.from_numpy(synth.frame_batch(256, N, 64)).to(dev).repeat(5, 1, 1)[:F4].contiguous()
+        frames4 = frames4 + 0.05 * torch.randn_like(frames4)          # 320 distinct windows: a full-rank covariance
+        dt = timed(lambda: fb4.mvdr_power(frames4, 1e-2), torch, 3)
+        out["mvdr_256_mics"] = {"maps_per_s": 1.0 / dt, "windows_per_map": F4, "bins": fb4.K, "grid": "57x32", "ms_per_map": dt * 1e3}
     finally:
         C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y = old
     return out
