@@ -187,3 +187,29 @@ def test_gpu_mvdr_256_mics_matches_float64_oracle(native):
         assert np.max(np.abs(got - want) / want) <= 5e-4          # conditioning of R^-1 in float32 at 256 mics
     finally:
         C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y = old
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,M,F,lo,nb", [(1024, 8, 3, 5, 300), (256, 5, 7, 0, 129), (512, 33, 2, 17, 97), (200, 4, 2, 3, 40)])
+def test_gpu_dft_matches_numpy_rfft(native, N, M, F, lo, nb):
+    """bf_fd_dft_device (twiddle GEMM on the matrix cores, bin groups beyond 128 bins) against numpy.fft.rfft, both layouts."""
+    import torch
+    from interface import config
+    config.configure(N_MICROPHONES=M, N_SAMPLES=N, MAX_RES_X=3, MAX_RES_Y=3, N_TAPS=8)
+    try:
+        rng = np.random.default_rng(N + nb)
+        sig = rng.standard_normal((F, M, N)).astype(np.float32)
+        mics = np.arange(M, dtype=np.int32)
+        d = torch.from_numpy(sig).cuda()
+        mk = lambda *s: torch.full(s, float("nan"), dtype=torch.float32, device="cuda")
+        re_mf, im_mf, re_fm, im_fm = mk(nb, M, F), mk(nb, M, F), mk(nb, F, M), mk(nb, F, M)
+        assert native.lib.bf_fd_dft_device(d.data_ptr(), M, F, native.iptr(mics), M, lo, nb, re_mf.data_ptr(), im_mf.data_ptr(), re_fm.data_ptr(),
+                                           im_fm.data_ptr(), None) == 0, native.check()
+        want = np.fft.rfft(sig.astype(np.float64), axis=2)[:, :, lo:lo + nb]          # [F, M, nb]
+        got_mf = re_mf.double().cpu().numpy() + 1j * im_mf.double().cpu().numpy()     # [nb, M, F]
+        got_fm = re_fm.double().cpu().numpy() + 1j * im_fm.double().cpu().numpy()     # [nb, F, M]
+        tol = 2e-6 * np.abs(want).max() * np.sqrt(N)
+        assert np.max(np.abs(got_mf - want.transpose(2, 1, 0))) <= tol
+        assert np.max(np.abs(got_fm - want.transpose(2, 0, 1))) <= tol
+    finally:
+        util.configure("cfg1")

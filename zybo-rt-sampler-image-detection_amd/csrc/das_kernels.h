@@ -96,7 +96,7 @@ hipError_t launch_power_center(const float* d_power, int frames, int rows, int c
 // with its three epilogues (phase-steer DAS power, covariance, MVDR quadratic form) plus the per-bin Cholesky inverse.
 hipError_t launch_fd_steering(const double* d_tau, const double* d_freq, int n_dirs, int n_mics, int n_bins, float* d_are, float* d_aim, hipStream_t stream);
 // Twiddle table of the MFMA DFT for (N, bin range): fd_twiddle_floats floats, built by launch_fd_twiddles.  launch_fd_dft
-// without a table (or with more than 128 bins) runs the plain one-workgroup-per-row kernel.
+// without a table runs the plain one-workgroup-per-row kernel.
 size_t fd_twiddle_floats(int n_samples, int n_bins);
 hipError_t launch_fd_twiddles(int n_samples, int bin_lo, int n_bins, float* d_tw, hipStream_t stream);
 hipError_t launch_fd_dft(const float* d_frames, const int32_t* d_mics, int m_total, int n_samples, int n_frames, int n_mics, int bin_lo, int n_bins,

@@ -298,13 +298,14 @@ __global__ void __launch_bounds__(256) twiddle_kernel(float* __restrict__ wc, fl
     }
 }
 
-template <int KT>   // 32-bin tiles per wave (bins padded to 32 KT)
+template <int KT>   // 32-bin tiles per wave; blockIdx.y walks groups of 32 KT bins of a table whose rows hold kp_total bins
 __global__ void __launch_bounds__(256) dft_mfma_kernel(const float* __restrict__ frames, const int32_t* __restrict__ mics, int m_total, int n_samples,
-                                                       int n_frames, int n_mics, int n_bins, const float* __restrict__ wc, const float* __restrict__ ws,
-                                                       float* __restrict__ xre_mf, float* __restrict__ xim_mf, float* __restrict__ xre_fm,
-                                                       float* __restrict__ xim_fm)
+                                                       int n_frames, int n_mics, int n_bins, int kp_total, const float* __restrict__ wc,
+                                                       const float* __restrict__ ws, float* __restrict__ xre_mf, float* __restrict__ xim_mf,
+                                                       float* __restrict__ xre_fm, float* __restrict__ xim_fm)
 {
-    constexpr int KP = 32 * KT, CH = 64;        // padded bins; samples per staged twiddle chunk
+    constexpr int KP = 32 * KT, CH = 64;        // bins of this group; samples per staged twiddle chunk
+    const int kofs = blockIdx.y * KP;
     extern __shared__ float tw[];               // [2][CH][KP]
     float* tc = tw;
     float* ts = tw + CH * KP;
@@ -323,9 +324,10 @@ __global__ void __launch_bounds__(256) dft_mfma_kernel(const float* __restrict__
     for (int n0 = 0; n0 < n_samples; n0 += CH) {
         __syncthreads();
         for (int i = threadIdx.x; i < CH * KP; i += blockDim.x) {
-            const int n = n0 + i / KP;
-            tc[i] = n < n_samples ? wc[(size_t)n0 * KP + i] : 0.0f;
-            ts[i] = n < n_samples ? ws[(size_t)n0 * KP + i] : 0.0f;
+            const int nn = i / KP, kk = i - nn * KP, n = n0 + nn;
+            const bool ok = n < n_samples && kofs + kk < kp_total;
+            tc[i] = ok ? wc[(size_t)n * kp_total + kofs + kk] : 0.0f;
+            ts[i] = ok ? ws[(size_t)n * kp_total + kofs + kk] : 0.0f;
         }
         __syncthreads();
 #pragma unroll 4
@@ -346,7 +348,7 @@ __global__ void __launch_bounds__(256) dft_mfma_kernel(const float* __restrict__
     for (int t = 0; t < KT; ++t)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int k = 32 * t + acc_row(q, lane);
+            const int k = kofs + 32 * t + acc_row(q, lane);
             if (k < n_bins) {
                 const size_t mf = ((size_t)k * n_mics + m) * n_frames + f, fm = ((size_t)k * n_frames + f) * n_mics + m;
                 xre_mf[mf] = are_[t][q]; xim_mf[mf] = aim_[t][q];
@@ -594,22 +596,26 @@ hipError_t launch_fd_twiddles(int n_samples, int bin_lo, int n_bins, float* d_tw
 hipError_t launch_fd_dft(const float* d_frames, const int32_t* d_mics, int m_total, int n_samples, int n_frames, int n_mics, int bin_lo, int n_bins,
                          const float* d_tw, float* xre_mf, float* xim_mf, float* xre_fm, float* xim_fm, hipStream_t stream)
 {
-    const int kt = (n_bins + 31) / 32;
-    if (d_tw == nullptr || kt > 4) {
-        // more than 128 bins (or no twiddle table): the plain kernel, one workgroup per (frame, mic)
+    const int kt_all = (n_bins + 31) / 32;
+    if (d_tw == nullptr) {
+        // no twiddle table: the plain kernel, one workgroup per (frame, mic)
         hipLaunchKernelGGL(dft_kernel, dim3((unsigned)(n_frames * n_mics)), dim3(128), (size_t)3 * n_samples * sizeof(float), stream, d_frames, d_mics, m_total,
                            n_samples, n_frames, n_mics, bin_lo, n_bins, xre_mf, xim_mf, xre_fm, xim_fm);
         return hipGetLastError();
     }
-    const int kp = kt * 32;
+    const int kp = kt_all * 32;                      // row length of the twiddle table (launch_fd_twiddles)
+    const int kt = kt_all > 4 ? 4 : kt_all;          // tiles per wave; more than 128 bins: several bin groups (blockIdx.y)
+    const int groups = (kt_all + kt - 1) / kt;
     const float* wc = d_tw;
     const float* ws = d_tw + (size_t)n_samples * kp;
     const long long rows = (long long)n_frames * n_mics;
-    const dim3 grid((unsigned)((rows + 127) / 128));
-    const size_t lds = (size_t)2 * 64 * kp * sizeof(float);
+    const dim3 grid((unsigned)((rows + 127) / 128), (unsigned)groups);
+    const size_t lds = (size_t)2 * 64 * (32 * kt) * sizeof(float);
     auto go = [&](auto kernel) -> hipError_t {
-        hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, d_frames, d_mics, m_total, n_samples, n_frames, n_mics, n_bins, wc, ws, xre_mf, xim_mf, xre_fm,
-                           xim_fm);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, d_frames, d_mics, m_total, n_samples, n_frames, n_mics, n_bins, kp, wc, ws, xre_mf, xim_mf,
+                           xre_fm, xim_fm);
         return hipGetLastError();
     };
     switch (kt) {
