@@ -213,3 +213,36 @@ def test_gpu_dft_matches_numpy_rfft(native, N, M, F, lo, nb):
         assert np.max(np.abs(got_fm - want.transpose(2, 0, 1))) <= tol
     finally:
         util.configure("cfg1")
+
+
+@pytest.mark.gpu
+def test_gpu_direction_shards_of_the_frequency_domain_maps(native):
+    """FrequencyBeamformer(dir_range=...) holds one shard of the steering phasors; shards put side by side (what
+    multi_gpu.sharded_heatmaps' all-gather does across ranks) equal the full-grid maps, DAS and MVDR."""
+    import torch
+    import freq_np as F
+    import multi_gpu
+    from realtime_scripts import beam_forming_algorithm as B, config as C
+    old = (C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y)
+    C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y = 64, 1, 13, 11
+    try:
+        t = F.tables(res_x=13, res_y=11, arrays=1)
+        frames = _scene(t, 4, 7, 96, np.random.default_rng(21)).astype(np.float32)
+        d_frames = torch.from_numpy(np.ascontiguousarray(frames.transpose(0, 2, 1))).cuda()
+        full = B.FrequencyBeamformer()
+        D = full.D
+        want_mvdr, want_das = full.mvdr_power(d_frames), full.das_power(d_frames[:5].contiguous())
+        parts_m, parts_d = [], []
+        for rank in range(3):                                   # the ranges three ranks would own
+            lo, hi = multi_gpu.shard_range(D, 3, rank)
+            fb = B.FrequencyBeamformer(dir_range=(lo, hi))
+            assert fb.D == hi - lo and fb.D_full == D
+            parts_m.append(fb.mvdr_power(d_frames))
+            parts_d.append(fb.das_power(d_frames[:5].contiguous()))
+        assert torch.allclose(torch.cat(parts_m), want_mvdr, rtol=1e-6, atol=0)
+        assert torch.allclose(torch.cat(parts_d, dim=1), want_das, rtol=1e-6, atol=0)
+        # world size 1: sharded_heatmaps degenerates to the compute function on the whole grid
+        one = multi_gpu.sharded_heatmaps(lambda lo, hi: B.FrequencyBeamformer(dir_range=(lo, hi)).mvdr_power(d_frames)[None, :], 1, D, device="cuda")
+        assert torch.allclose(one[0], want_mvdr, rtol=1e-6, atol=0)
+    finally:
+        C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y = old

@@ -65,7 +65,9 @@ def scan_tables(active=None):
 class FrequencyBeamformer:
     """Steering phasors resident in HBM; batched phase-steer DAS and MVDR over windows that are already on the device."""
 
-    def __init__(self, active=None, device="cuda"):
+    def __init__(self, active=None, device="cuda", dir_range=None):
+        """`dir_range=(lo, hi)`: keep the steering phasors of the flat directions [lo, hi) only -- one rank's shard when the
+        grid is split over GPUs (multi_gpu.sharded_heatmaps); the maps returned then have hi - lo columns."""
         import torch
         if not torch.cuda.is_available():
             raise nat.BeamformerError("no usable HIP device; the frequency-domain beamformers have no CPU fallback")
@@ -74,6 +76,11 @@ class FrequencyBeamformer:
         self.active = np.ascontiguousarray(active_microphones() if active is None else active, dtype=np.int32)
         self.freq, self.bin_lo, self.bin_hi, tau, self.x_scan, self.y_scan = scan_tables(self.active)
         self.K, self.M, self.D = len(self.freq), len(self.active), config.MAX_RES_X * config.MAX_RES_Y
+        self.dir_lo, self.dir_hi = (0, self.D) if dir_range is None else (int(dir_range[0]), int(dir_range[1]))
+        if not 0 <= self.dir_lo < self.dir_hi <= self.D:
+            raise ValueError("dir_range %r outside the %d-direction grid" % (dir_range, self.D))
+        tau = np.ascontiguousarray(tau[self.dir_lo:self.dir_hi])
+        self.D_full, self.D = self.D, self.dir_hi - self.dir_lo
         nat.lib.bf_configure(config.N_MICROPHONES, config.N_SAMPLES, config.MAX_RES_X, config.MAX_RES_Y, 8)
         nat.check()
         d_tau = torch.from_numpy(tau).to(device)
@@ -107,7 +114,8 @@ class FrequencyBeamformer:
         return p
 
     def das_heatmap(self, d_frames):
-        """beam_forming_algorithm.py:58-63: zero when the maximum is under the threshold, else divided by the maximum."""
+        """beam_forming_algorithm.py:58-63: zero when the maximum is under the threshold, else divided by the maximum.
+        (With a `dir_range` the maximum is the shard's: normalise after assembling the shards instead.)"""
         p = self.das_power(d_frames)
         mx = p.amax(dim=1, keepdim=True)
         return self.torch.where(mx < threshold_heatmap, self.torch.zeros_like(p), p / mx)
