@@ -409,3 +409,31 @@ def test_beamformer_producer_loops(nat, oracle_lib):
     finally:
         B.audio_sink = None
         B.disconnect()
+
+
+@pytest.mark.parametrize("algo", ["pad", "lerp"])
+def test_batched_random_tables_every_step_reloads(nat, oracle_lib, algo):
+    """A table with no structure (independent random delays per direction and mic): the sweep kernel's worst case, every
+    direction step re-reads its quads.  Batched device path, 5 frames, against the oracle frame by frame."""
+    torch = _torch()
+    from interface import config
+    M, N, X, Y, T, F = 64, 256, 24, 23, 8, 5
+    config.configure(N_MICROPHONES=M, N_SAMPLES=N, MAX_RES_X=X, MAX_RES_Y=Y, N_TAPS=T)
+    rng = np.random.default_rng(77)
+    delays = rng.uniform(0, 40.0, size=(X, Y, M))
+    table = delays.astype(int).astype(np.int32) if algo == "pad" else np.float32(delays)
+    frames = (rng.standard_normal((F, M, N)) * 0.25).astype(np.float32)
+    mics = np.arange(M, dtype=np.int32)
+    orc = oracle_lib.Oracle(N, X, Y, T)
+    orc.load(ALGOS[algo], table)
+    run_product(nat, algo, table, frames[0], mics)          # loads the table into the library
+    D = X * Y
+    d_sig = torch.from_numpy(frames).cuda()
+    d_img = torch.full((F, D), float("nan"), dtype=torch.float32, device="cuda")
+    assert nat.lib.bf_das_device(ALGOS[algo], d_sig.data_ptr(), M, d_img.data_ptr(), D, F, nat.iptr(mics), M, 0, D,
+                                 torch.cuda.current_stream().cuda_stream) == 0, nat.check()
+    torch.cuda.synchronize()
+    got = d_img.cpu().numpy()
+    for f in range(F):
+        want = orc.mimo_range(ALGOS[algo], frames[f], mics, 0, D)
+        assert max_rel(got[f], want) <= REL_TOL, f
