@@ -122,6 +122,11 @@ def timed(fn, torch, iters, warm=2):
     return (time.perf_counter() - t0) / iters
 
 
+def config_dirs():
+    from interface import config
+    return config.MAX_RES_X * config.MAX_RES_Y
+
+
 def extras(torch, nat, delays, mics, dev):
     """The other single-GPU BASELINE configs, measured after the headline run (each a few hundred ms):
     config 3 MVDR (64 mics, 101x101), config 4 fused heat-map -> 640x640 overlay -> YOLOv5s detection, plus the
@@ -131,6 +136,19 @@ def extras(torch, nat, delays, mics, dev):
     from realtime_scripts import beam_forming_algorithm as B, config as C
     out = {}
     M, N = 64, 256
+    # the other time-domain flavours on the headline workload (same launch shape: 190 frames resident in HBM)
+    Dn = config_dirs()
+    win190 = torch.from_numpy(synth.frame_batch(M, N, 64)).to(dev).repeat(3, 1, 1)[:190].contiguous()
+    img190 = torch.empty((190, Dn), dtype=torch.float32, device=dev)
+    for name, algo_id, loader, table in (
+            ("time_domain_pad", nat.PAD, nat.lib.load_coefficients_pad, np.ascontiguousarray(delays.astype(int).astype(np.int32)).ravel()),
+            ("time_domain_hybrid", nat.HYBRID, nat.lib.load_coefficients_convolve_hybrid, np.ascontiguousarray(np.float32(delays)).ravel())):
+        loader(nat.iptr(table) if table.dtype == np.int32 else nat.fptr(table), table.size)
+        nat.check()
+        s0 = torch.cuda.current_stream().cuda_stream
+        dt = timed(lambda: nat.lib.bf_das_device(algo_id, win190.data_ptr(), M, img190.data_ptr(), Dn, 190, nat.iptr(mics), M, 0, Dn, s0), torch, 5)
+        nat.check()
+        out[name] = {"frames_per_s": 190 / dt, "ms_per_launch": dt * 1e3}
     # config 4
     pipe = FusedPipeline("lerp", 640, dev)
     pipe.load_tables(delays, mics)
