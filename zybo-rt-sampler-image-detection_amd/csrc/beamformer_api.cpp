@@ -68,6 +68,7 @@ struct TableSet {
     DevBuf<float> taps;
     DevBuf<int32_t> digest;   // shifted-copies layout: LDS offsets per (direction, mic), see bf::launch_digest
     DigestKey digest_key;     // what the digest was built for
+    bool digest_direct = false; // ... in the [D][M] layout of the direction-outer kernel variant (table without structure)
     void drop() { loaded = false; entries = 0; max_whole = 0; digest_key = DigestKey{}; whole.release(); frac.release(); taps.release(); digest.release(); }
 };
 
@@ -86,6 +87,7 @@ struct State {
     // scratch for the host-pointer entry points
     DevBuf<float> d_frame, d_image, d_out, d_init, d_one_taps, d_one_frac;
     DevBuf<int32_t> d_mics, d_one_whole;
+    DevBuf<unsigned long long> d_counter;  // digest build: direction steps that change the delay
     DevBuf<float> fd_work;               // partial planes of the bin-reducing GEMMs (bf::fd_workspace_floats)
     DevBuf<float> fd_chol_work;          // blocks of the 129..256-mic Cholesky / inverse (bf::fd_cholesky_workspace_floats)
     DevBuf<float> fd_tw;                 // twiddles of the MFMA DFT for (N, bin_lo, n_bins) = fd_tw_key
@@ -296,12 +298,28 @@ bool ensure_digest(TableSet& t, bf::DasLaunch& L, const bf::DasPlan& plan, hipSt
     // everything the digest depends on: the plan's geometry, the algorithm and (grouped layouts) the direction range
     const DigestKey key{true, plan.mic_chunk, plan.row_stride, plan.lead, L.algo, plan.dpw, L.dir_begin, L.dir_end, L.n_mics};
     if (!(t.digest_key == key) || !t.digest.p) {
-        if (!HIP_OK(t.digest.reserve(bf::digest_elements(L, plan)))) return false;
-        if (!HIP_OK(bf::launch_digest(L, plan, t.digest.p, stream))) return false;
+        State& s = S();
+        if (!HIP_OK(t.digest.reserve(bf::digest_elements(L, plan))) || !HIP_OK(s.d_counter.reserve(1))) return false;
+        t.digest_direct = false;
+        const bool grouped = L.algo == bf::ALGO_PAD || L.algo == bf::ALGO_LERP;
+        if (grouped && !HIP_OK(hipMemsetAsync(s.d_counter.p, 0, sizeof(unsigned long long), stream))) return false;
+        if (!HIP_OK(bf::launch_digest(L, plan, t.digest.p, grouped ? s.d_counter.p : nullptr, false, stream))) return false;
         // once per (table, layout): wait, so that a later launch on ANOTHER stream cannot overtake the digest's construction
         if (!HIP_OK(hipStreamSynchronize(stream))) return false;
+        if (grouped && plan.waves == 16) {
+            // A table without structure (more than half of the direction steps change the delay) defeats the sweep: use the
+            // direction-outer kernel variant and its [D][M] digest instead.
+            unsigned long long reloads = 0;
+            if (!HIP_OK(hipMemcpy(&reloads, s.d_counter.p, sizeof(reloads), hipMemcpyDeviceToHost))) return false;
+            const long long steps = bf::digest_shareable_steps(L, plan);
+            if (steps > 0 && 2 * (long long)reloads > steps) {
+                if (!HIP_OK(bf::launch_digest(L, plan, t.digest.p, nullptr, true, stream)) || !HIP_OK(hipStreamSynchronize(stream))) return false;
+                t.digest_direct = true;
+            }
+        }
         t.digest_key = key;
     }
+    L.tab.digest_direct = t.digest_direct;
     L.tab.digest = t.digest.p;
     return true;
 }

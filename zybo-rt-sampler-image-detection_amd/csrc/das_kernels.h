@@ -22,6 +22,7 @@ struct DeviceTables {
     const float* frac = nullptr;     // [D][M]      h = 1 - frac              (lerp)
     const float* taps = nullptr;     // [D][M][T]   FIR taps                  (hybrid, fir)
     int max_whole = 0;               // max over the table, clamped to N (sizes the zero prefix in LDS)
+    bool digest_direct = false;      // digest is in the [D][M] layout: run the direction-outer (DIRECT) kernel variant
     const int32_t* digest = nullptr; // LDS byte offsets for the shifted-copies layout (launch_digest): grouped by the wave's directions for pad / lerp
                                      // (+ the lerp weights in the same order), [D][M] for hybrid; null when not built
 };
@@ -69,7 +70,10 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why);
 
 // Build DeviceTables::digest for the layout `plan` describes (shifted-copies layout only).
 size_t digest_elements(const DasLaunch& L, const DasPlan& plan);   // 4-byte elements the digest of this launch needs (0: none)
-hipError_t launch_digest(const DasLaunch& L, const DasPlan& plan, int32_t* d_digest, hipStream_t stream);
+// `direct`: the [D][M] layout of the direction-outer kernel variant (tables without structure) instead of the grouped one;
+// d_reload_count (grouped build, optional) receives the number of direction steps whose delay differs from the previous one's.
+hipError_t launch_digest(const DasLaunch& L, const DasPlan& plan, int32_t* d_digest, unsigned long long* d_reload_count, bool direct, hipStream_t stream);
+long long digest_shareable_steps(const DasLaunch& L, const DasPlan& plan);
 
 // Enqueue on `stream`; no host synchronisation, no allocation (graph-capturable).
 hipError_t launch_das(const DasLaunch& L, const DasPlan& plan, hipStream_t stream);

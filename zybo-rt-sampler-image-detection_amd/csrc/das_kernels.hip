@@ -24,6 +24,7 @@
 // resource is VALU issue.  See DESIGN.md section 5 for the byte / instruction accounting.
 #include "das_kernels.h"
 
+#include <algorithm>
 #include <type_traits>
 
 namespace bf {
@@ -642,7 +643,8 @@ __global__ void __launch_bounds__(256) digest_kernel(const int32_t* __restrict__
 // are never stored).
 __global__ void __launch_bounds__(256) digest_grouped_kernel(const int32_t* __restrict__ whole, const float* __restrict__ frac, int32_t* __restrict__ digest,
                                                              long long entries, long long h_off, int n_mics, int gdirs, int dir_begin, int dir_end,
-                                                             int mic_chunk, int arrays, int row_stride, int lead, int bias)
+                                                             int mic_chunk, int arrays, int row_stride, int lead, int bias,
+                                                             unsigned long long* __restrict__ reload_count)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < entries; i += (long long)gridDim.x * blockDim.x) {
         const int j = (int)(i % gdirs);
@@ -667,6 +669,12 @@ __global__ void __launch_bounds__(256) digest_grouped_kernel(const int32_t* __re
         }
         digest[i] = entry;
         if (frac != nullptr) reinterpret_cast<float*>(digest)[h_off + i] = frac[d * n_mics + mic];
+        if (reload_count != nullptr && j > 0) {
+            // how often the sweep will have to re-read: this direction's delay differs from the previous direction's
+            // (directions past the end repeat the last one: never a change)
+            const long long dn = dir_begin + g * gdirs + j;
+            if (dn <= dir_end - 1 && whole[(d - 1) * n_mics + mic] != whole[d * n_mics + mic]) atomicAdd(reload_count, 1ull);
+        }
     }
 }
 
@@ -894,7 +902,8 @@ __device__ __forceinline__ void lerp_quad(f32x2 (&ac)[2], const Quad& q, const Q
 // per (direction, mic)), fetched with s_load_dwordx16 like the lerp weights in `frac`.  Per (direction, mic, segment)
 // the wave issues  pad: 1 ds_read_b128 + 2 v_pk_add_f32;  lerp: 2 ds_read_b128 + 2 v_pk_fma_f32 + 2 v_pk_add_f32, plus
 // one v_add per (direction, mic) for the address (two for lerp with a run-time row stride).
-template <int ALGO, int NSEG, int RS, int W>
+// DIRECT: direction-outer inner loop with a [D][M] digest, for pad / lerp tables without structure (see `directions`).
+template <int ALGO, int NSEG, int RS, int W, bool DIRECT = false>
 __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, KArgs a)
 {
     constexpr bool FIR = ALGO == ALGO_HYBRID || ALGO == ALGO_FIR_NAIVE || ALGO == ALGO_FIR_VEC;   // 8 taps, N <= 256
@@ -1121,6 +1130,85 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
                     acc[j][0][1] = f32x2{o[2], o[3]};
                 }
             };
+            // DIRECT variant (tables without structure: neighbouring directions do not share delays, so the sweep below would
+            // reload -- and wait -- at every step): one direction at a time, its staged mics in order, U mics x NSEG segments
+            // of reads kept in flight.  Digest [D][M] and the lerp weights straight from `frac`, 16 entries per s_load.
+            auto directions = [&](auto mcc_c) {
+                // MCC > 0: the chunk's mic count at compile time (a whole number of batches): straight-line code, no
+                // per-mic conditionals.  MCC == 0: any count, one uniform branch per batch.
+                constexpr int MCC = decltype(mcc_c)::value;
+                constexpr bool FULL = MCC > 0;
+                constexpr int U = Geo<NSEG>::kBatch;
+                static_assert(MCC % U == 0, "whole batches");
+#pragma unroll
+                for (int j = 0; j < DW; ++j) {
+                    const int d = g0 + wave * DW + j;           // wave-uniform
+                    if (d >= tile_end) continue;
+                    const size_t idx = (size_t)d * M + m0;
+                    // 16 entries unconditionally (the tables carry 64 bytes of slack) so the loads merge into wide s_loads
+                    int e[16];
+                    float hh[16];
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) {
+                        e[m] = dig[idx + m];
+                        hh[m] = 0.0f;
+                        if constexpr (ALGO == ALGO_LERP) hh[m] = frac[idx + m];
+                    }
+                    auto consume = [&](const float4& Sq, const float4& Dv, float h, f32x2 (&ac)[2]) {
+                        const f32x2 S01{Sq.x, Sq.y}, S23{Sq.z, Sq.w};
+                        if constexpr (ALGO == ALGO_PAD) {
+                            // pad_and_sum.c:41-47   out[k] += s[k - p]
+                            ac[0] += S01; ac[1] += S23;
+                        } else {
+                            // lerp_and_sum.c:50-56  out[k] += s[i] + h * (s[i+1] - s[i]),  i = k - p - 1
+                            const f32x2 h2{h, h}, D01{Dv.x, Dv.y}, D23{Dv.z, Dv.w};
+                            ac[0] += __builtin_elementwise_fma(h2, D01, S01);
+                            ac[1] += __builtin_elementwise_fma(h2, D23, S23);
+                        }
+                    };
+                    if constexpr (FULL) {
+                        // software pipeline over the (mic, segment) units of this direction: R units' reads in flight,
+                        // each consumed unit's registers are refilled at once
+                        constexpr int R = 4, UNITS = MCC * NSEG;
+                        float4 S[R], Dq[R];
+                        auto issue = [&](int i, int slot) {
+                            const char* sp = lbase + e[i / NSEG] + 1024 * (i % NSEG);
+                            S[slot] = *reinterpret_cast<const float4*>(sp);
+                            if constexpr (ALGO == ALGO_LERP) Dq[slot] = *reinterpret_cast<const float4*>(sp + 16 * rs);   // D copies: 4 rows on
+                        };
+#pragma unroll
+                        for (int i = 0; i < R; ++i) issue(i, i);
+#pragma unroll
+                        for (int i = 0; i < UNITS; ++i) {
+                            consume(S[i % R], Dq[i % R], hh[i / NSEG], acc[j][i % NSEG]);
+                            if (i + R < UNITS) issue(i + R, i % R);
+                        }
+                    } else {
+#pragma unroll
+                        for (int mb = 0; mb < 16; mb += U) {
+                            if (mb >= mcc) break;
+                            float4 S[U][NSEG], Dq[U][NSEG];
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                // a partial batch re-reads mic 0's row for the missing mics and drops the result
+                                const int eo = (mb + u < mcc) ? e[mb + u] : e[0];
+                                const char* sp = lbase + eo;
+#pragma unroll
+                                for (int sg = 0; sg < NSEG; ++sg) {
+                                    S[u][sg] = *reinterpret_cast<const float4*>(sp + 1024 * sg);
+                                    if constexpr (ALGO == ALGO_LERP) Dq[u][sg] = *reinterpret_cast<const float4*>(sp + 16 * rs + 1024 * sg);
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                if (mb + u >= mcc) break;
+#pragma unroll
+                                for (int sg = 0; sg < NSEG; ++sg) consume(S[u][sg], Dq[u][sg], hh[mb + u], acc[j][sg]);
+                            }
+                        }
+                    }
+                }
+            };
             // pad / lerp: mic-outer sweep over the wave's DW directions.  Neighbouring directions mostly share a mic's
             // whole-sample delay (the delay changes by a fraction of a sample per grid step), and the LDS read depends on
             // nothing else: the quad (and its difference quad) is re-read only when the offset differs from the previous
@@ -1213,6 +1301,16 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
                 if (mcc == 16) fir_directions(std::integral_constant<int, 16>{});
                 else if (mcc == 8) fir_directions(std::integral_constant<int, 8>{});
                 else fir_directions(std::integral_constant<int, 0>{});
+            } else if constexpr (DIRECT) {
+                // N <= 256: the chunk sizes the planner picks get straight-line code.  With more segments the 64 accumulator
+                // registers leave no room for the deeper read pipelining that buys (it spills), so only the branchy form.
+                if constexpr (NSEG == 1) {
+                    if (mcc == 16) directions(std::integral_constant<int, 16>{});
+                    else if (mcc == 8) directions(std::integral_constant<int, 8>{});
+                    else directions(std::integral_constant<int, 0>{});
+                } else {
+                    directions(std::integral_constant<int, 0>{});
+                }
             } else {
                 sweep();
             }
@@ -1298,10 +1396,18 @@ hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, in
             if constexpr (!kFir && NSEG == 1) {
                 if (plan.waves == 8) kernel = fixed ? copies::das_copies_kernel<ALGO, NSEG, kRs, 8> : copies::das_copies_kernel<ALGO, NSEG, 0, 8>;
             }
+            bool direct = false;
+            if constexpr (!kFir) {
+                if (L.tab.digest_direct) {
+                    if (plan.waves != copies::kWaves) return hipErrorInvalidValue;      // the DIRECT variant exists for 16 waves only
+                    kernel = fixed ? copies::das_copies_kernel<ALGO, NSEG, kRs, copies::kWaves, true> : copies::das_copies_kernel<ALGO, NSEG, 0, copies::kWaves, true>;
+                    direct = true;
+                }
+            }
             if (plan.waves != copies::kWaves && !(plan.waves == 8 && !kFir && NSEG == 1)) return hipErrorInvalidValue;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
             if (e != hipSuccess) return e;
-            if constexpr (!kFir && NSEG == 1) {
+            if constexpr (!kFir && NSEG == 1) if (!direct) {
                 // This variant keeps LDS reads in flight across asm statements (issue_quads / await_quads): sound only while
                 // the compiler neither spills nor copies those registers.  Spilling is checkable: refuse to run a build that
                 // uses scratch (copies would show in the bit-exact parity tests).
@@ -1511,26 +1617,34 @@ long long grouped_entries(const DasLaunch& L, const DasPlan& plan) { return grou
 size_t digest_elements(const DasLaunch& L, const DasPlan& plan)
 {
     if (plan.layout != 2) return 0;
-    if (L.algo == ALGO_PAD) return (size_t)grouped_entries(L, plan);
-    if (L.algo == ALGO_LERP) return (size_t)(2 * grouped_entries(L, plan));    // offsets, then the lerp weights in the same order
+    const size_t direct = (size_t)L.n_dirs * (size_t)L.n_mics;                 // the [D][M] layout of the DIRECT variant
+    if (L.algo == ALGO_PAD) return std::max((size_t)grouped_entries(L, plan), direct);
+    if (L.algo == ALGO_LERP) return std::max((size_t)(2 * grouped_entries(L, plan)), direct);    // offsets, then the lerp weights in the same order
     if (L.algo == ALGO_HYBRID) return (size_t)L.n_dirs * (size_t)L.n_mics;
     return 0;
 }
 
-hipError_t launch_digest(const DasLaunch& L, const DasPlan& plan, int32_t* d_digest, hipStream_t stream)
+hipError_t launch_digest(const DasLaunch& L, const DasPlan& plan, int32_t* d_digest, unsigned long long* d_reload_count, bool direct, hipStream_t stream)
 {
     // what the kernel looks back by beyond the whole-sample delay: lerp reads s[k - p - 1], hybrid starts its window at
     // s[k - p - 1 - T/2] (T = 8)
     const int arrays = (L.algo == ALGO_LERP) ? 2 : 1, bias = (L.algo == ALGO_LERP) ? 1 : (L.algo == ALGO_HYBRID) ? 5 : 0;
-    if (L.algo == ALGO_HYBRID) {
+    if (L.algo == ALGO_HYBRID || direct) {
         hipLaunchKernelGGL(digest_kernel, dim3(1024), dim3(256), 0, stream, L.tab.whole, d_digest, (long long)L.n_dirs * L.n_mics, L.n_mics, plan.mic_chunk,
                            arrays, plan.row_stride, plan.lead, bias);
     } else {
         const long long entries = grouped_entries(L, plan);
         hipLaunchKernelGGL(digest_grouped_kernel, dim3(1024), dim3(256), 0, stream, L.tab.whole, L.algo == ALGO_LERP ? L.tab.frac : nullptr, d_digest,
-                           entries, entries, L.n_mics, plan.dpw, L.dir_begin, L.dir_end, plan.mic_chunk, arrays, plan.row_stride, plan.lead, bias);
+                           entries, entries, L.n_mics, plan.dpw, L.dir_begin, L.dir_end, plan.mic_chunk, arrays, plan.row_stride, plan.lead, bias,
+                           d_reload_count);
     }
     return hipGetLastError();
+}
+
+// Steps of a launch over which the sweep can share reads at all (all but the first direction of every group).
+long long digest_shareable_steps(const DasLaunch& L, const DasPlan& plan)
+{
+    return plan.dpw > 1 ? grouped_entries(L, plan) / plan.dpw * (plan.dpw - 1) : 0;
 }
 
 hipError_t launch_das(const DasLaunch& L, const DasPlan& plan, hipStream_t stream)
