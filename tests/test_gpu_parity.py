@@ -275,6 +275,7 @@ def test_batched_device_path(nat, algo):
     assert nat.lib.bf_das_device(ALGOS[algo], d_sig.data_ptr(), M, d_img.data_ptr(), D, F, nat.iptr(mics), M, 0, D, stream) == 0
     torch.cuda.synchronize()
     assert np.array_equal(d_img.cpu().numpy(), ref_imgs)
+    assert nat.lib.bf_last_das_variant() == 2          # geometric tables: the sweep with shared reads
     # two direction shards, as two ranks would compute them
     cut = 5003
     lo = torch.full((F, cut), float("nan"), dtype=torch.float32, device="cuda")
@@ -433,6 +434,7 @@ def test_batched_random_tables_every_step_reloads(nat, oracle_lib, algo):
     assert nat.lib.bf_das_device(ALGOS[algo], d_sig.data_ptr(), M, d_img.data_ptr(), D, F, nat.iptr(mics), M, 0, D,
                                  torch.cuda.current_stream().cuda_stream) == 0, nat.check()
     torch.cuda.synchronize()
+    assert nat.lib.bf_last_das_variant() == 3          # the digest build found no structure: direction-outer variant
     got = d_img.cpu().numpy()
     for f in range(F):
         want = orc.mimo_range(ALGOS[algo], frames[f], mics, 0, D)

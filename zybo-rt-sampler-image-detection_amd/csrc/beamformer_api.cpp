@@ -96,6 +96,7 @@ struct State {
     std::vector<float> published;        // bf_publish_frame / get_data
     std::vector<int> disabled_mics;      // get_data's dead-microphone rows
     bool disabled_default = true;
+    int last_variant = -1;               // bf_last_das_variant
     std::string err;
 };
 
@@ -294,6 +295,7 @@ bool plan_or_error(bf::DasLaunch& L, bf::DasPlan* plan)
 // Shifted-copies layout with scalar tables: make sure the table set carries a digest built for this plan.
 bool ensure_digest(TableSet& t, bf::DasLaunch& L, const bf::DasPlan& plan, hipStream_t stream)
 {
+    S().last_variant = plan.layout == 2 ? 4 : plan.layout;          // refined below for the digest-driven kernels
     if (plan.layout != 2 || L.algo == bf::ALGO_FIR_NAIVE || L.algo == bf::ALGO_FIR_VEC) return true;   // the plain FIRs have no whole-sample table
     // everything the digest depends on: the plan's geometry, the algorithm and (grouped layouts) the direction range
     const DigestKey key{true, plan.mic_chunk, plan.row_stride, plan.lead, L.algo, plan.dpw, L.dir_begin, L.dir_end, L.n_mics};
@@ -321,6 +323,7 @@ bool ensure_digest(TableSet& t, bf::DasLaunch& L, const bf::DasPlan& plan, hipSt
     }
     L.tab.digest_direct = t.digest_direct;
     L.tab.digest = t.digest.p;
+    S().last_variant = (L.algo == bf::ALGO_PAD || L.algo == bf::ALGO_LERP) ? (t.digest_direct ? 3 : 2) : 4;
     return true;
 }
 
@@ -530,6 +533,10 @@ void bf_get_config(int out[5])
 
 const char* bf_last_error(void) { return S().err.c_str(); }
 void bf_clear_error(void) { S().err.clear(); }
+
+// Which kernel family the last delay-and-sum launch used: 0 strided, 1 quad + DPP, 2 shifted copies / sweep, 3 shifted copies /
+// direction-outer (table without structure), 4 shifted copies / 8-tap FIR; -1 before the first launch.  For tests and tuning.
+int bf_last_das_variant(void) { return S().last_variant; }
 
 int bf_gpu_available(void)
 {

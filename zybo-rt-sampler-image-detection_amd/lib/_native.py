@@ -77,6 +77,7 @@ _sig("bf_get_config", None, IP)
 _sig("bf_last_error", C.c_char_p)
 _sig("bf_clear_error", None)
 _sig("bf_gpu_available", C.c_int)
+_sig("bf_last_das_variant", C.c_int)
 _sig("bf_set_device", C.c_int, C.c_int)
 _sig("bf_publish_frame", None, FP)
 _sig("bf_das_device", C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, IP, C.c_int, C.c_int, C.c_int, C.c_void_p)
