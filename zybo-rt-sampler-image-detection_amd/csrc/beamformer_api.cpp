@@ -58,6 +58,22 @@ struct DigestKey {
     }
 };
 
+// Page-locked host staging buffer (the host-pointer entry points copy through it: DMA straight from / to pinned memory
+// instead of the runtime's own staging of pageable memory).
+struct PinnedBuf {
+    float* p = nullptr;
+    size_t cap = 0;   // floats
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), n * sizeof(float), hipHostMallocDefault);
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+};
+
 // One loaded coefficient set (what a load_coefficients_* call leaves behind).
 struct TableSet {
     bool loaded = false;
@@ -88,6 +104,7 @@ struct State {
     DevBuf<float> d_frame, d_image, d_out, d_init, d_one_taps, d_one_frac;
     DevBuf<int32_t> d_mics, d_one_whole;
     DevBuf<unsigned long long> d_counter;  // digest build: direction steps that change the delay
+    PinnedBuf h_frame, h_image;          // host-pointer mimo_*: pinned staging of the frame in / the image out
     DevBuf<float> fd_work;               // partial planes of the bin-reducing GEMMs (bf::fd_workspace_floats)
     DevBuf<float> fd_chol_work;          // blocks of the 129..256-mic Cholesky / inverse (bf::fd_cholesky_workspace_floats)
     DevBuf<float> fd_tw;                 // twiddles of the MFMA DFT for (N, bin_lo, n_bins) = fd_tw_key
@@ -344,14 +361,17 @@ void run_mimo_host(int algo, int slot, const float* signals, float* image, const
     if (ok) {
         const size_t rows = (size_t)max_row + 1;
         L.m_total = (int)rows;
-        ok = HIP_OK(s.d_frame.reserve(rows * s.sz.n_samples)) && HIP_OK(s.d_image.reserve(D));
-        ok = ok && HIP_OK(hipMemcpyAsync(s.d_frame.p, signals, rows * s.sz.n_samples * sizeof(float), hipMemcpyHostToDevice, s.stream));
+        const size_t frame_floats = rows * s.sz.n_samples;
+        ok = HIP_OK(s.d_frame.reserve(frame_floats)) && HIP_OK(s.d_image.reserve(D)) && HIP_OK(s.h_frame.reserve(frame_floats)) && HIP_OK(s.h_image.reserve(D));
+        if (ok) std::memcpy(s.h_frame.p, signals, frame_floats * sizeof(float));
+        ok = ok && HIP_OK(hipMemcpyAsync(s.d_frame.p, s.h_frame.p, frame_floats * sizeof(float), hipMemcpyHostToDevice, s.stream));
         L.signals = s.d_frame.p; L.images = s.d_image.p; L.mics = s.d_mics.p;
         ok = ok && plan_or_error(L, &plan);
         ok = ok && ensure_digest(s.tab[slot], L, plan, s.stream);
         ok = ok && HIP_OK(bf::launch_das(L, plan, s.stream));
-        ok = ok && HIP_OK(hipMemcpyAsync(image, s.d_image.p, D * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+        ok = ok && HIP_OK(hipMemcpyAsync(s.h_image.p, s.d_image.p, D * sizeof(float), hipMemcpyDeviceToHost, s.stream));
         ok = ok && HIP_OK(hipStreamSynchronize(s.stream));
+        if (ok) std::memcpy(image, s.h_image.p, D * sizeof(float));
     }
     if (!ok) poison(image, D);
 }
