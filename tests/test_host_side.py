@@ -66,18 +66,18 @@ def test_plan_geometry(native):
     """LDS sizing / tiling chosen on the host for the BASELINE sizes (no GPU needed)."""
     out = (C.c_longlong * 10)()
     util.configure("cfg2")
-    # lerp at N = 256: shifted-copies layout, 16 mics x (4 sample copies + 4 difference copies) per chunk, one 1024-thread
+    # lerp at N = 256: shifted-copies layout, 32 mics x (2 sample copies + 2 difference copies) per chunk, one 1024-thread
     # workgroup per CU, 8 directions per wave; small delays get the compile-time row stride (lead 48)
     assert native.lib.bf_plan_das(native.LERP, 64, 190, 0, 101 * 101, 12, 256, out) == 0
     nc, lead, rs, mc, nch, waves, dpw, tile, ntiles, lds = list(out)
-    assert (nc, mc, nch, waves, dpw) == (4, 16, 4, 16, 8) and lds <= 160 * 1024 and tile % 128 == 0 and ntiles % 8 == 0
+    assert (nc, mc, nch, waves, dpw) == (4, 32, 2, 16, 8) and lds <= 160 * 1024 and tile % 128 == 0 and ntiles % 8 == 0
     assert (lead, rs) == (48, 304)
     assert native.lib.bf_plan_das(native.PAD, 64, 190, 0, 101 * 101, 12, 256, out) == 0
-    assert list(out)[3:5] == [16, 4] and out[9] == 128 * 260 * 4      # the parked power rows outgrow the pad chunk
-    # larger delays: run-time row stride, and the lerp chunk drops to 8 mics
+    assert list(out)[3:5] == [32, 2] and out[9] == 128 * 260 * 4      # the parked power rows outgrow the pad chunk
+    # larger delays: run-time row stride (the two-copy rows still leave room for 16 mics per chunk)
     assert native.lib.bf_plan_das(native.LERP, 64, 190, 0, 101 * 101, 95, 256, out) == 0
     nc, lead, rs, mc, nch, waves, dpw, tile, ntiles, lds = list(out)
-    assert (lead, rs, mc, nch) == (100, 356, 8, 8) and lds <= 160 * 1024
+    assert (lead, rs, mc, nch) == (100, 356, 16, 4) and lds <= 160 * 1024
     # N = 1024: one strided copy per mic row, chunked over the mics, 4 directions carried per wave
     util.configure("cfg5")
     assert native.lib.bf_plan_das(native.LERP, 256, 1, 0, 361 * 361, 47, 256, out) == 0

@@ -310,7 +310,7 @@ bool plan_or_error(bf::DasLaunch& L, bf::DasPlan* plan)
 }
 
 // Shifted-copies layout with scalar tables: make sure the table set carries a digest built for this plan.
-bool ensure_digest(TableSet& t, bf::DasLaunch& L, const bf::DasPlan& plan, hipStream_t stream)
+bool ensure_digest(TableSet& t, bf::DasLaunch& L, bf::DasPlan& plan, hipStream_t stream)
 {
     S().last_variant = plan.layout == 2 ? 4 : plan.layout;          // refined below for the digest-driven kernels
     if (plan.layout != 2 || L.algo == bf::ALGO_FIR_NAIVE || L.algo == bf::ALGO_FIR_VEC) return true;   // the plain FIRs have no whole-sample table
@@ -332,11 +332,16 @@ bool ensure_digest(TableSet& t, bf::DasLaunch& L, const bf::DasPlan& plan, hipSt
             if (!HIP_OK(hipMemcpy(&reloads, s.d_counter.p, sizeof(reloads), hipMemcpyDeviceToHost))) return false;
             const long long steps = bf::digest_shareable_steps(L, plan);
             if (steps > 0 && 2 * (long long)reloads > steps) {
+                L.tab.digest_direct = true;
+                if (!plan_or_error(L, &plan)) return false;     // that variant reads at every step: four shifted copies, its own chunk size
                 if (!HIP_OK(bf::launch_digest(L, plan, t.digest.p, nullptr, true, stream)) || !HIP_OK(hipStreamSynchronize(stream))) return false;
                 t.digest_direct = true;
             }
         }
-        t.digest_key = key;
+        t.digest_key = key;                                     // (the key is the sweep plan's: what the caller's planning yields next time)
+    } else if (t.digest_direct) {
+        L.tab.digest_direct = true;
+        if (!plan_or_error(L, &plan)) return false;
     }
     L.tab.digest_direct = t.digest_direct;
     L.tab.digest = t.digest.p;

@@ -22,7 +22,7 @@ struct DeviceTables {
     const float* frac = nullptr;     // [D][M]      h = 1 - frac              (lerp)
     const float* taps = nullptr;     // [D][M][T]   FIR taps                  (hybrid, fir)
     int max_whole = 0;               // max over the table, clamped to N (sizes the zero prefix in LDS)
-    bool digest_direct = false;      // digest is in the [D][M] layout: run the direction-outer (DIRECT) kernel variant
+    bool digest_direct = false;      // digest is in the [D][M] layout: run the direction-outer (DIRECT) kernel variant (plan_das sizes the chunk for its four copies)
     const int32_t* digest = nullptr; // LDS byte offsets for the shifted-copies layout (launch_digest): grouped by the wave's directions for pad / lerp
                                      // (+ the lerp weights in the same order), [D][M] for hybrid; null when not built
 };
@@ -60,6 +60,7 @@ struct DasPlan {
     int quad;        // 1: lane owns 4 consecutive samples (ds_read_b128 + DPP), 0: lane-strided samples (ds_read_b32)
     int layout;      // 0 strided, 1 quad + DPP, 2 shifted copies (pad / lerp, N <= 256)
     int dpw;         // directions a wave carries across mic chunks
+    int copies;      // layout 2: shifted copies per staged array (2: the sweep of pad / lerp, 4: FIR flavours and the DIRECT variant)
     int tile_dirs;   // directions per workgroup
     int n_tiles;     // padded to a multiple of 8 (XCD affinity: tile % 8 == workgroup id % 8)
     size_t lds_bytes;

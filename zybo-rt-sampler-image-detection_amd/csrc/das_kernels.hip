@@ -627,12 +627,12 @@ __global__ void __launch_bounds__(64) das_miso_kernel(BF_TABLE_PARAMS, const flo
 // direction d reads for staged mic m % mic_chunk (copy (p & 3), shifted back by p >> 2 quads; lerp reads one sample
 // earlier, p + 1).  Built once per (table, layout) so that the hot loop gets its addresses with scalar loads only.
 __global__ void __launch_bounds__(256) digest_kernel(const int32_t* __restrict__ whole, int32_t* __restrict__ digest, long long entries, int n_mics,
-                                                     int mic_chunk, int arrays, int row_stride, int lead, int bias)
+                                                     int mic_chunk, int arrays, int row_stride, int lead, int bias, int ncopies)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < entries; i += (long long)gridDim.x * blockDim.x) {
         const int m = (int)(i % n_mics) % mic_chunk;
         const int pd = whole[i] + bias;
-        digest[i] = ((m * arrays * 4 + (pd & 3)) * row_stride + lead - (pd & ~3)) * 4;
+        digest[i] = ((m * arrays * ncopies + (pd & (ncopies - 1))) * row_stride + lead - (pd & ~(ncopies - 1))) * 4;
     }
 }
 
@@ -643,7 +643,7 @@ __global__ void __launch_bounds__(256) digest_kernel(const int32_t* __restrict__
 // are never stored).
 __global__ void __launch_bounds__(256) digest_grouped_kernel(const int32_t* __restrict__ whole, const float* __restrict__ frac, int32_t* __restrict__ digest,
                                                              long long entries, long long h_off, int n_mics, int gdirs, int dir_begin, int dir_end,
-                                                             int mic_chunk, int arrays, int row_stride, int lead, int bias,
+                                                             int mic_chunk, int arrays, int row_stride, int lead, int bias, int ncopies,
                                                              unsigned long long* __restrict__ reload_count)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < entries; i += (long long)gridDim.x * blockDim.x) {
@@ -655,9 +655,9 @@ __global__ void __launch_bounds__(256) digest_grouped_kernel(const int32_t* __re
         if (d > dir_end - 1) d = dir_end - 1;
         const int m = mic % mic_chunk;
         const int pd = whole[d * n_mics + mic] + bias;
-        int entry = ((m * arrays * 4 + (pd & 3)) * row_stride + lead - (pd & ~3)) * 4;
+        int entry = ((m * arrays * ncopies + (pd & (ncopies - 1))) * row_stride + lead - (pd & ~(ncopies - 1))) * 4;
         if (j == 0) {
-            // offsets are multiples of 16: bit 0 of a group's first entry says "every direction of the group reads the same
+            // offsets are multiples of 8: bit 0 of a group's first entry says "every direction of the group reads the same
             // quads of this mic" (one read, no per-direction test in the kernel)
             bool same = true;
             for (int jj = 1; jj < gdirs; ++jj) {
@@ -691,6 +691,11 @@ __device__ __forceinline__ float dpp_next(float x)   // lane+1's value, 0 in lan
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float lane_value(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+
+// Shifted copies kept per staged array.  The sweep of pad / lerp re-reads rarely and reads 8-byte halves: one copy per
+// delay mod 2 is enough (half the staging writes and half the LDS per mic).  The kernels that read at every step -- the
+// 8-tap FIR flavours and the direction-outer (DIRECT) variant of pad / lerp -- need ds_read_b128: one copy per delay mod 4.
+__host__ __device__ constexpr int copies_of(int algo, bool direct) { return ((algo == ALGO_PAD || algo == ALGO_LERP) && !direct) ? 2 : 4; }
 
 // Geometry of the shifted-copies layout for a block of NSEG x 256 samples (N <= 256: 1, <= 512: 2, <= 1024: 4).
 //   * a wave owns DW directions x NSEG segments of 256 samples (one aligned quad per lane per segment);
@@ -742,19 +747,24 @@ struct Staged {
     float edge;   // NSEG > 1: lanes 0..2 hold s[4q-3 .. 4q-1] of the segment's first quad, lane 63 holds s[4q+4] of its last
 };
 
-// Write the four shifted copies of a segment: copy c holds the row shifted right by c samples, i.e. its aligned
+// Write the NC shifted copies of a segment: copy c holds the row shifted right by c samples, i.e. its aligned
 // quad i is (x[4i-c], ..., x[4i-c+3]); (py, pz, pw) are x[4q-3 .. 4q-1] (previous lane, or the segment edge).
+// NC = 4 serves 16-byte reads at any delay (the FIR flavours' ds_read_b128), NC = 2 the 8-byte reads of pad / lerp.
+template <int NC>
 __device__ __forceinline__ void write_copies(float* row0, int rs, int col, int lane, float4 v, float py, float pz, float pw)
 {
     float4* q0 = reinterpret_cast<float4*>(row0 + 0 * rs + col) + lane;
     float4* q1 = reinterpret_cast<float4*>(row0 + 1 * rs + col) + lane;
-    float4* q2 = reinterpret_cast<float4*>(row0 + 2 * rs + col) + lane;
-    float4* q3 = reinterpret_cast<float4*>(row0 + 3 * rs + col) + lane;
     *q0 = v;
     *q1 = make_float4(pw, v.x, v.y, v.z);
-    *q2 = make_float4(pz, pw, v.x, v.y);
-    *q3 = make_float4(py, pz, pw, v.x);
+    if constexpr (NC == 4) {
+        float4* q2 = reinterpret_cast<float4*>(row0 + 2 * rs + col) + lane;
+        float4* q3 = reinterpret_cast<float4*>(row0 + 3 * rs + col) + lane;
+        *q2 = make_float4(pz, pw, v.x, v.y);
+        *q3 = make_float4(py, pz, pw, v.x);
+    }
 }
+
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -910,8 +920,11 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
     static_assert(!FIR || NSEG == 1, "the FIR flavours use the one-segment geometry");
     static_assert(RS == 0 || RS == (FIR ? Geo<NSEG>::kRsFir : Geo<NSEG>::kRs), "fixed row stride");
     constexpr int A = (ALGO == ALGO_LERP) ? 2 : 1;   // arrays per mic: s (and D)
+    constexpr int C = copies_of(ALGO, DIRECT);        // shifted copies per array
     constexpr int DW = Geo<NSEG>::kDw, kGroup = DW * W, kPark = Geo<NSEG>::kPark;   // kGroup: directions per workgroup pass
-    constexpr int SP = ((NSEG > 1 && ALGO == ALGO_PAD) ? 32 : 16) / W;   // (mic, segment) pairs a wave stages per chunk
+    // (mic, segment) pairs a wave stages per chunk: 16 per workgroup, 32 where the two-copy rows leave room for them
+    // (pad with several segments; the one-segment sweep with 16 waves: 32-mic chunks, half the barriers)
+    constexpr int SP = (((NSEG > 1 && ALGO == ALGO_PAD) || (NSEG == 1 && W == 16 && !FIR && !DIRECT)) ? 32 : 16) / W;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -927,7 +940,7 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
     float* __restrict__ img = images + (size_t)frame * a.image_stride;
     // the digest rides in a pointer slot the algorithm does not use: taps (pad, lerp) or frac (hybrid)
     const int32_t* __restrict__ dig = reinterpret_cast<const int32_t*>(FIR ? frac : taps);
-    const int slot_floats = A * 4 * rs;   // floats per staged mic
+    const int slot_floats = A * C * rs;   // floats per staged mic
 
     // Rows of `signals` this wave stages: pair index pr = wave + W i  <->  chunk mic pr / NSEG, segment pr % NSEG.
     // The mic ids of the first 64 chunks are loaded once (lane c holds chunk c's) so that the per-chunk prefetch is a
@@ -981,7 +994,7 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
                 if (lane == 0) { py = ey; pz = ez; pw = ew; }
                 if (lane == 63) nx = en;
             }
-            write_copies(row0, rs, col, lane, v, py, pz, pw);
+            write_copies<C>(row0, rs, col, lane, v, py, pz, pw);
             if constexpr (FIR) {
                 // the zero padding after the block (convolve_and_sum.c:199-203): quad 64 of copy c still holds the last c
                 // samples, quad 65 is zero
@@ -1004,13 +1017,13 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
                 if constexpr (NSEG > 1) {
                     if (lane == 0 && seg > 0) { dy = ez - ey; dz = ew - ez; dw = v.x - ew; }
                 }
-                write_copies(row0 + 4 * rs, rs, col, lane, dq, dy, dz, dw);
+                write_copies<C>(row0 + C * rs, rs, col, lane, dq, dy, dz, dw);
             }
             if (seg == 0) {   // the zero prefix (also wiped by the parked rows of the previous group); lead can exceed 256
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int q = lane; q < (lead >> 2); q += kWave) {
 #pragma unroll
-                    for (int c = 0; c < 4 * A; ++c) reinterpret_cast<float4*>(row0 + c * rs)[q] = z;
+                    for (int c = 0; c < C * A; ++c) reinterpret_cast<float4*>(row0 + c * rs)[q] = z;
                 }
             }
         }
@@ -1174,7 +1187,7 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
                         auto issue = [&](int i, int slot) {
                             const char* sp = lbase + e[i / NSEG] + 1024 * (i % NSEG);
                             S[slot] = *reinterpret_cast<const float4*>(sp);
-                            if constexpr (ALGO == ALGO_LERP) Dq[slot] = *reinterpret_cast<const float4*>(sp + 16 * rs);   // D copies: 4 rows on
+                            if constexpr (ALGO == ALGO_LERP) Dq[slot] = *reinterpret_cast<const float4*>(sp + 4 * C * rs);   // D copies: C rows on
                         };
 #pragma unroll
                         for (int i = 0; i < R; ++i) issue(i, i);
@@ -1196,7 +1209,7 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
 #pragma unroll
                                 for (int sg = 0; sg < NSEG; ++sg) {
                                     S[u][sg] = *reinterpret_cast<const float4*>(sp + 1024 * sg);
-                                    if constexpr (ALGO == ALGO_LERP) Dq[u][sg] = *reinterpret_cast<const float4*>(sp + 16 * rs + 1024 * sg);
+                                    if constexpr (ALGO == ALGO_LERP) Dq[u][sg] = *reinterpret_cast<const float4*>(sp + 4 * C * rs + 1024 * sg);
                                 }
                             }
 #pragma unroll
@@ -1223,7 +1236,7 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
                 const float* __restrict__ hg = reinterpret_cast<const float*>(dig) + a.digest_h_off + (grp * M + m0) * DW;
                 // LDS byte address of this lane's quad column (the asm reads need the raw 32-bit LDS address)
                 const int lb = 16 * lane + (int)(unsigned)(size_t)((__attribute__((address_space(3))) char*)lds);
-                const int d_off = 16 * rs;                      // D copies sit 4 rows after the s copies
+                const int d_off = 4 * C * rs;                   // D copies sit C rows after the s copies
                 constexpr bool kLerp = ALGO == ALGO_LERP;
                 struct Entries { int e[DW]; unsigned long long hp[DW / 2]; };   // offsets; lerp weights as (even, odd) direction pairs
                 auto request = [&](Entries& t, int m) {
@@ -1252,21 +1265,21 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
                 constexpr bool kPipe = NSEG == 1;
                 request(E[0], 0);
                 request(E[1], 1);
-                if constexpr (kPipe) issue_quads<NSEG, kLerp>(S[0], Dq[0], E[0].e[0] & ~15, lb, d_off);
+                if constexpr (kPipe) issue_quads<NSEG, kLerp>(S[0], Dq[0], E[0].e[0] & ~7, lb, d_off);
                 auto mic = [&](int m, auto pc, auto kc) {
                     constexpr int P = kPipe ? decltype(pc)::value : 0, K = decltype(kc)::value, K1 = (K + 1) % 3, K2 = (K + 2) % 3;
                     const Entries& cur = E[K];
                     if constexpr (kPipe) {
                         await_quads<NSEG>(S[P], Dq[P]);
-                        issue_quads<NSEG, kLerp>(S[P ^ 1], Dq[P ^ 1], E[K1].e[0] & ~15, lb, d_off);
+                        issue_quads<NSEG, kLerp>(S[P ^ 1], Dq[P ^ 1], E[K1].e[0] & ~7, lb, d_off);
                         request(E[K2], m + 2);
                     } else {
                         request(E[K2], m + 2);
-                        reload_quads<NSEG, kLerp>(S[P], Dq[P], cur.e[0] & ~15, -1, lb, d_off);   // offsets are >= 0: -1 always loads (and waits)
+                        reload_quads<NSEG, kLerp>(S[P], Dq[P], cur.e[0] & ~7, -1, lb, d_off);   // offsets are >= 0: -1 always loads (and waits)
                     }
                     auto stepj = [&](auto jc) {
                         constexpr int j = decltype(jc)::value;
-                        if constexpr (j > 0) reload_quads<NSEG, kLerp>(S[P], Dq[P], cur.e[j], j == 1 ? (cur.e[0] & ~15) : cur.e[j - 1], lb, d_off);
+                        if constexpr (j > 0) reload_quads<NSEG, kLerp>(S[P], Dq[P], cur.e[j], j == 1 ? (cur.e[0] & ~7) : cur.e[j - 1], lb, d_off);
 #pragma unroll
                         for (int sg = 0; sg < NSEG; ++sg) {
                             if constexpr (ALGO == ALGO_PAD) add_quad(acc[j][sg], S[P][sg]);
@@ -1560,18 +1573,20 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
         p.lead = round_up(back + 1, 4);
         if (p.lead <= fixed_lead && !(L.debug & 2)) p.lead = fixed_lead;   // compile-time row stride
         p.row_stride = p.lead + nseg * 256 + (fir ? copies::Geo<1>::kFirTail : 0);
-        const size_t slot_bytes = (size_t)arrays * 4 * p.row_stride * sizeof(float);
+        p.copies = copies::copies_of(L.algo, L.tab.digest_direct);
+        const size_t slot_bytes = (size_t)arrays * p.copies * p.row_stride * sizeof(float);
         // a chunk: as many mics as fit beside nothing else in 156 KiB, at most 16 (one s_load of table entries) and at
         // most what the 16 waves stage in one go (one (mic, segment) pair each; two for pad with several segments)
-        const int stage_pairs = 16 * ((nseg > 1 && L.algo == ALGO_PAD) ? 2 : 1);
+        int stage_pairs = 16 * ((nseg > 1 && L.algo == ALGO_PAD) ? 2 : 1);
         // One 16-wave workgroup per CU with (nearly) the whole LDS.  pad / lerp at N <= 256 also come as 8-wave workgroups
         // (two per CU, 78 KiB each): twice the staging per direction, so only for grids too coarse to fill 16 waves' 128
         // directions (cfg1: 121 directions, 637K -> 961K frames/s).  (cfg2, 190 frames: 16 waves 80.0K, 8 waves 72.0K.)
-        const int waves = (plain && nseg == 1 && (L.dir_end - L.dir_begin) < 256) ? 8 : copies::kWaves;
+        const int waves = (plain && nseg == 1 && ((L.dir_end - L.dir_begin) < 256 || (L.debug & 4))) ? 8 : copies::kWaves;   // debug bit 2: A/B switch
         const size_t budget = waves == 8 ? (size_t)78 * 1024 : (size_t)156 * 1024;
+        if (plain && nseg == 1 && waves == copies::kWaves && !L.tab.digest_direct && !(L.debug & 8)) stage_pairs = 32;   // debug bit 3: A/B switch
         int mc = (int)(budget / slot_bytes);
         if (mc > stage_pairs / nseg) mc = stage_pairs / nseg;
-        mc = mc >= 16 ? 16 : mc >= 8 ? 8 : mc >= 4 ? 4 : mc >= 2 ? 2 : mc;
+        mc = mc >= 32 ? 32 : mc >= 16 ? 16 : mc >= 8 ? 8 : mc >= 4 ? 4 : mc >= 2 ? 2 : mc;
         if (mc < 1) return fail(3);
         if (mc > L.n_mics) mc = L.n_mics;
         p.mic_chunk = mc; p.n_chunks = (L.n_mics + mc - 1) / mc;
@@ -1631,12 +1646,12 @@ hipError_t launch_digest(const DasLaunch& L, const DasPlan& plan, int32_t* d_dig
     const int arrays = (L.algo == ALGO_LERP) ? 2 : 1, bias = (L.algo == ALGO_LERP) ? 1 : (L.algo == ALGO_HYBRID) ? 5 : 0;
     if (L.algo == ALGO_HYBRID || direct) {
         hipLaunchKernelGGL(digest_kernel, dim3(1024), dim3(256), 0, stream, L.tab.whole, d_digest, (long long)L.n_dirs * L.n_mics, L.n_mics, plan.mic_chunk,
-                           arrays, plan.row_stride, plan.lead, bias);
+                           arrays, plan.row_stride, plan.lead, bias, plan.copies);
     } else {
         const long long entries = grouped_entries(L, plan);
         hipLaunchKernelGGL(digest_grouped_kernel, dim3(1024), dim3(256), 0, stream, L.tab.whole, L.algo == ALGO_LERP ? L.tab.frac : nullptr, d_digest,
                            entries, entries, L.n_mics, plan.dpw, L.dir_begin, L.dir_end, plan.mic_chunk, arrays, plan.row_stride, plan.lead, bias,
-                           d_reload_count);
+                           plan.copies, d_reload_count);
     }
     return hipGetLastError();
 }
