@@ -5,7 +5,7 @@ import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] else os.path.join(ROOT, "zybo-rt-sampler-image-detection_amd", "csrc", "das_kernels.hip")
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "--cuda-device-only",
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fno-jump-tables", "--cuda-device-only",
        "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
 err = subprocess.run(cmd, stderr=subprocess.PIPE, text=True).stderr
 cur = None

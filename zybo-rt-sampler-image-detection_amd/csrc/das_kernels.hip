@@ -885,21 +885,88 @@ __device__ __forceinline__ void lerp_quad(f32x2 (&ac)[2], const Quad& q, const Q
 {
     // lerp_and_sum.c:50-56  out[k] += s[i] + h * (s[i+1] - s[i]),  i = k - p - 1   (gcc contracts it into one fma)
     // The weights of two neighbouring directions arrive as one aligned SGPR pair straight from s_load; op_sel picks the half.
-    f32x2 t0, t1;
+    // The products go through v[124:127], named as clobbers instead of compiler-chosen outputs: with outputs the register
+    // allocator reuses them for the address temporaries of the next asm statement, and the hazard recogniser then puts an
+    // s_nop between the two statements at every step (an issue slot like any other instruction: 9 % of the kernel).
     if constexpr (HALF == 0) {
-        asm volatile("v_pk_fma_f32 %[t0], %[h], %[dl], %[ql] op_sel_hi:[0,1,1]\n\t"
-                     "v_pk_fma_f32 %[t1], %[h], %[dh], %[qh] op_sel_hi:[0,1,1]\n\t"
-                     "v_pk_add_f32 %[a0], %[a0], %[t0]\n\t"
-                     "v_pk_add_f32 %[a1], %[a1], %[t1]"
-                     : [a0] "+v"(ac[0]), [a1] "+v"(ac[1]), [t0] "=&v"(t0), [t1] "=&v"(t1)
-                     : [h] "s"(hp), [dl] "v"(d.lo), [dh] "v"(d.hi), [ql] "v"(q.lo), [qh] "v"(q.hi));
+        asm volatile("v_pk_fma_f32 v[124:125], %[h], %[dl], %[ql] op_sel_hi:[0,1,1]\n\t"
+                     "v_pk_fma_f32 v[126:127], %[h], %[dh], %[qh] op_sel_hi:[0,1,1]\n\t"
+                     "v_pk_add_f32 %[a0], %[a0], v[124:125]\n\t"
+                     "v_pk_add_f32 %[a1], %[a1], v[126:127]"
+                     : [a0] "+v"(ac[0]), [a1] "+v"(ac[1])
+                     : [h] "s"(hp), [dl] "v"(d.lo), [dh] "v"(d.hi), [ql] "v"(q.lo), [qh] "v"(q.hi)
+                     : "v124", "v125", "v126", "v127");
     } else {
-        asm volatile("v_pk_fma_f32 %[t0], %[h], %[dl], %[ql] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-                     "v_pk_fma_f32 %[t1], %[h], %[dh], %[qh] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-                     "v_pk_add_f32 %[a0], %[a0], %[t0]\n\t"
-                     "v_pk_add_f32 %[a1], %[a1], %[t1]"
-                     : [a0] "+v"(ac[0]), [a1] "+v"(ac[1]), [t0] "=&v"(t0), [t1] "=&v"(t1)
-                     : [h] "s"(hp), [dl] "v"(d.lo), [dh] "v"(d.hi), [ql] "v"(q.lo), [qh] "v"(q.hi));
+        asm volatile("v_pk_fma_f32 v[124:125], %[h], %[dl], %[ql] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                     "v_pk_fma_f32 v[126:127], %[h], %[dh], %[qh] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                     "v_pk_add_f32 %[a0], %[a0], v[124:125]\n\t"
+                     "v_pk_add_f32 %[a1], %[a1], v[126:127]"
+                     : [a0] "+v"(ac[0]), [a1] "+v"(ac[1])
+                     : [h] "s"(hp), [dl] "v"(d.lo), [dh] "v"(d.hi), [ql] "v"(q.lo), [qh] "v"(q.hi)
+                     : "v124", "v125", "v126", "v127");
+    }
+}
+
+// Four direction steps (4 H .. 4 H + 3) of the one-segment sweep as ONE asm statement: per step the offset test with its
+// out-of-line re-read (as reload_quads) and the step's arithmetic (as add_quad / lerp_quad).  Between two asm statements
+// that pass registers to each other the compiler inserts an s_nop (it cannot see that the registers the first one "wrote"
+// are ready): an issue slot per step when every step is its own pair of statements, 9 % of the kernel's instructions.
+// lerp: the products go through v[124:127], named as clobbers (no operands left to spend, and no compiler-chosen
+// temporaries that it could share with the next statement's address registers).
+#define BF_Q_CHECK(j, ep, ec) "s_cmp_lg_u32 %[" #ec "], %[" #ep "]\n\ts_cbranch_scc1 .Lr" #j "_%=\n.Lb" #j "_%=:\n\t"
+#define BF_Q_PAD(j) "v_pk_add_f32 %[a" #j "0], %[a" #j "0], %[sl]\n\tv_pk_add_f32 %[a" #j "1], %[a" #j "1], %[sh]\n\t"
+#define BF_Q_LERP(j, h, mods)                                                    \
+    "v_pk_fma_f32 v[124:125], %[" #h "], %[dl], %[sl] " mods "\n\t"              \
+    "v_pk_fma_f32 v[126:127], %[" #h "], %[dh], %[sh] " mods "\n\t"              \
+    "v_pk_add_f32 %[a" #j "0], %[a" #j "0], v[124:125]\n\t"                      \
+    "v_pk_add_f32 %[a" #j "1], %[a" #j "1], v[126:127]\n\t"
+#define BF_Q_PAD_RELOAD(j, ec)                                                   \
+    ".Lr" #j "_%=:\n\tv_add_u32 %[ad], %[" #ec "], %[lb]\n\t"                    \
+    "ds_read_b64 %[sl], %[ad] offset:0\n\tds_read_b64 %[sh], %[ad] offset:8\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\ts_branch .Lb" #j "_%=\n"
+#define BF_Q_LERP_RELOAD(j, ec)                                                  \
+    ".Lr" #j "_%=:\n\tv_add_u32 %[ad], %[" #ec "], %[lb]\n\tv_add_u32 %[ad2], %[ad], %[doff]\n\t" \
+    "ds_read_b64 %[sl], %[ad] offset:0\n\tds_read_b64 %[sh], %[ad] offset:8\n\t" \
+    "ds_read_b64 %[dl], %[ad2] offset:0\n\tds_read_b64 %[dh], %[ad2] offset:8\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\ts_branch .Lb" #j "_%=\n"
+#define BF_Q_EVEN "op_sel_hi:[0,1,1]"
+#define BF_Q_ODD "op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+#define BF_Q_ACC(j, i) [a##j##0] "+v"(acc[i][0][0]), [a##j##1] "+v"(acc[i][0][1])
+template <bool LERP, int H>
+__device__ __forceinline__ void steps4(f32x2 (&acc)[8][1][2], Quad& S, Quad& D, int ep, int e0, int e1, int e2, int e3,
+                                       unsigned long long hlo, unsigned long long hhi, int lbase, int d_off)
+{
+    // e0..e3: LDS offsets of directions 4 H .. 4 H + 3; ep: the offset the quads hold on entry (H = 0: e0 itself -- the
+    // mic's first quads were requested a mic ahead, so its first step has no test)
+    int ad, ad2;
+    constexpr int B = 4 * H;
+    if constexpr (!LERP && H == 0) {
+        asm volatile(BF_Q_PAD(0) BF_Q_CHECK(1, e0, e1) BF_Q_PAD(1) BF_Q_CHECK(2, e1, e2) BF_Q_PAD(2) BF_Q_CHECK(3, e2, e3) BF_Q_PAD(3)
+                     ".subsection 1\n" BF_Q_PAD_RELOAD(1, e1) BF_Q_PAD_RELOAD(2, e2) BF_Q_PAD_RELOAD(3, e3) "\t.subsection 0"
+                     : BF_Q_ACC(0, B), BF_Q_ACC(1, B + 1), BF_Q_ACC(2, B + 2), BF_Q_ACC(3, B + 3), [sl] "+v"(S.lo), [sh] "+v"(S.hi), [ad] "=&v"(ad)
+                     : [e0] "s"(e0), [e1] "s"(e1), [e2] "s"(e2), [e3] "s"(e3), [lb] "v"(lbase) : "scc");
+    } else if constexpr (!LERP) {
+        asm volatile(BF_Q_CHECK(0, ep, e0) BF_Q_PAD(0) BF_Q_CHECK(1, e0, e1) BF_Q_PAD(1) BF_Q_CHECK(2, e1, e2) BF_Q_PAD(2) BF_Q_CHECK(3, e2, e3) BF_Q_PAD(3)
+                     ".subsection 1\n" BF_Q_PAD_RELOAD(0, e0) BF_Q_PAD_RELOAD(1, e1) BF_Q_PAD_RELOAD(2, e2) BF_Q_PAD_RELOAD(3, e3) "\t.subsection 0"
+                     : BF_Q_ACC(0, B), BF_Q_ACC(1, B + 1), BF_Q_ACC(2, B + 2), BF_Q_ACC(3, B + 3), [sl] "+v"(S.lo), [sh] "+v"(S.hi), [ad] "=&v"(ad)
+                     : [ep] "s"(ep), [e0] "s"(e0), [e1] "s"(e1), [e2] "s"(e2), [e3] "s"(e3), [lb] "v"(lbase) : "scc");
+    } else if constexpr (H == 0) {
+        asm volatile(BF_Q_LERP(0, h0, BF_Q_EVEN) BF_Q_CHECK(1, e0, e1) BF_Q_LERP(1, h0, BF_Q_ODD) BF_Q_CHECK(2, e1, e2) BF_Q_LERP(2, h1, BF_Q_EVEN)
+                         BF_Q_CHECK(3, e2, e3) BF_Q_LERP(3, h1, BF_Q_ODD)
+                     ".subsection 1\n" BF_Q_LERP_RELOAD(1, e1) BF_Q_LERP_RELOAD(2, e2) BF_Q_LERP_RELOAD(3, e3) "\t.subsection 0"
+                     : BF_Q_ACC(0, B), BF_Q_ACC(1, B + 1), BF_Q_ACC(2, B + 2), BF_Q_ACC(3, B + 3), [sl] "+v"(S.lo), [sh] "+v"(S.hi), [dl] "+v"(D.lo),
+                       [dh] "+v"(D.hi), [ad] "=&v"(ad), [ad2] "=&v"(ad2)
+                     : [e0] "s"(e0), [e1] "s"(e1), [e2] "s"(e2), [e3] "s"(e3), [h0] "s"(hlo), [h1] "s"(hhi), [lb] "v"(lbase), [doff] "s"(d_off)
+                     : "scc", "v124", "v125", "v126", "v127");
+    } else {
+        asm volatile(BF_Q_CHECK(0, ep, e0) BF_Q_LERP(0, h0, BF_Q_EVEN) BF_Q_CHECK(1, e0, e1) BF_Q_LERP(1, h0, BF_Q_ODD) BF_Q_CHECK(2, e1, e2)
+                         BF_Q_LERP(2, h1, BF_Q_EVEN) BF_Q_CHECK(3, e2, e3) BF_Q_LERP(3, h1, BF_Q_ODD)
+                     ".subsection 1\n" BF_Q_LERP_RELOAD(0, e0) BF_Q_LERP_RELOAD(1, e1) BF_Q_LERP_RELOAD(2, e2) BF_Q_LERP_RELOAD(3, e3) "\t.subsection 0"
+                     : BF_Q_ACC(0, B), BF_Q_ACC(1, B + 1), BF_Q_ACC(2, B + 2), BF_Q_ACC(3, B + 3), [sl] "+v"(S.lo), [sh] "+v"(S.hi), [dl] "+v"(D.lo),
+                       [dh] "+v"(D.hi), [ad] "=&v"(ad), [ad2] "=&v"(ad2)
+                     : [ep] "s"(ep), [e0] "s"(e0), [e1] "s"(e1), [e2] "s"(e2), [e3] "s"(e3), [h0] "s"(hlo), [h1] "s"(hhi), [lb] "v"(lbase),
+                       [doff] "s"(d_off)
+                     : "scc", "v124", "v125", "v126", "v127");
     }
 }
 
@@ -1255,14 +1322,15 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
                 //   mic m + 2 its table entries are requested.
                 // Two quad sets alternate by mic parity, three entry sets rotate: six mics per loop trip, no register copies.
                 Entries E[3];
-                Quad S[2][NSEG], Dq[2][NSEG];
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int sg = 0; sg < NSEG; ++sg) S[q][sg].lo = S[q][sg].hi = Dq[q][sg].lo = Dq[q][sg].hi = f32x2{0.0f, 0.0f};
                 // The cross-mic quad prefetch is used for one segment only: with more segments the 64 accumulators make the
                 // compiler spill, and a register with a read in flight must not be moved behind the asm statements' back.
                 constexpr bool kPipe = NSEG == 1;
+                constexpr int NQ = kPipe ? 2 : 1;              // quad sets: one per mic parity with the prefetch, else one
+                Quad S[NQ][NSEG], Dq[NQ][NSEG];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int sg = 0; sg < NSEG; ++sg) S[q][sg].lo = S[q][sg].hi = Dq[q][sg].lo = Dq[q][sg].hi = f32x2{0.0f, 0.0f};
                 request(E[0], 0);
                 request(E[1], 1);
                 if constexpr (kPipe) issue_quads<NSEG, kLerp>(S[0], Dq[0], E[0].e[0] & ~7, lb, d_off);
@@ -1277,24 +1345,31 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
                         request(E[K2], m + 2);
                         reload_quads<NSEG, kLerp>(S[P], Dq[P], cur.e[0] & ~7, -1, lb, d_off);   // offsets are >= 0: -1 always loads (and waits)
                     }
-                    auto stepj = [&](auto jc) {
-                        constexpr int j = decltype(jc)::value;
-                        if constexpr (j > 0) reload_quads<NSEG, kLerp>(S[P], Dq[P], cur.e[j], j == 1 ? (cur.e[0] & ~7) : cur.e[j - 1], lb, d_off);
+                    if constexpr (NSEG == 1) {
+                        static_assert(DW == 8, "two statements of four direction steps");
+                        const int e0 = cur.e[0] & ~7;
+                        steps4<kLerp, 0>(acc, S[P][0], Dq[P][0], e0, e0, cur.e[1], cur.e[2], cur.e[3], cur.hp[0], cur.hp[1], lb, d_off);
+                        steps4<kLerp, 1>(acc, S[P][0], Dq[P][0], cur.e[3], cur.e[4], cur.e[5], cur.e[6], cur.e[7], cur.hp[2], cur.hp[3], lb, d_off);
+                    } else {
+                        auto stepj = [&](auto jc) {
+                            constexpr int j = decltype(jc)::value;
+                            if constexpr (j > 0) reload_quads<NSEG, kLerp>(S[P], Dq[P], cur.e[j], j == 1 ? (cur.e[0] & ~7) : cur.e[j - 1], lb, d_off);
 #pragma unroll
-                        for (int sg = 0; sg < NSEG; ++sg) {
-                            if constexpr (ALGO == ALGO_PAD) add_quad(acc[j][sg], S[P][sg]);
-                            else lerp_quad<j & 1>(acc[j][sg], S[P][sg], Dq[P][sg], cur.hp[j / 2]);
+                            for (int sg = 0; sg < NSEG; ++sg) {
+                                if constexpr (ALGO == ALGO_PAD) add_quad(acc[j][sg], S[P][sg]);
+                                else lerp_quad<j & 1>(acc[j][sg], S[P][sg], Dq[P][sg], cur.hp[j / 2]);
+                            }
+                        };
+                        stepj(std::integral_constant<int, 0>{});
+                        stepj(std::integral_constant<int, 1>{});
+                        stepj(std::integral_constant<int, 2>{});
+                        stepj(std::integral_constant<int, 3>{});
+                        if constexpr (DW == 8) {
+                            stepj(std::integral_constant<int, 4>{});
+                            stepj(std::integral_constant<int, 5>{});
+                            stepj(std::integral_constant<int, 6>{});
+                            stepj(std::integral_constant<int, 7>{});
                         }
-                    };
-                    stepj(std::integral_constant<int, 0>{});
-                    stepj(std::integral_constant<int, 1>{});
-                    stepj(std::integral_constant<int, 2>{});
-                    stepj(std::integral_constant<int, 3>{});
-                    if constexpr (DW == 8) {
-                        stepj(std::integral_constant<int, 4>{});
-                        stepj(std::integral_constant<int, 5>{});
-                        stepj(std::integral_constant<int, 6>{});
-                        stepj(std::integral_constant<int, 7>{});
                     }
                 };
                 using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
@@ -1308,7 +1383,7 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
                 }
                 // nothing may stay in flight into registers the compiler is about to reuse
                 await_quads<NSEG>(S[0], Dq[0]);
-                await_quads<NSEG>(S[1], Dq[1]);
+                if constexpr (kPipe) await_quads<NSEG>(S[NQ - 1], Dq[NQ - 1]);
             };
             if constexpr (FIR) {
                 if (mcc == 16) fir_directions(std::integral_constant<int, 16>{});
