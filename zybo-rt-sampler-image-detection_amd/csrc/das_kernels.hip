@@ -655,19 +655,7 @@ __global__ void __launch_bounds__(256) digest_grouped_kernel(const int32_t* __re
         if (d > dir_end - 1) d = dir_end - 1;
         const int m = mic % mic_chunk;
         const int pd = whole[d * n_mics + mic] + bias;
-        int entry = ((m * arrays * ncopies + (pd & (ncopies - 1))) * row_stride + lead - (pd & ~(ncopies - 1))) * 4;
-        if (j == 0) {
-            // offsets are multiples of 8: bit 0 of a group's first entry says "every direction of the group reads the same
-            // quads of this mic" (one read, no per-direction test in the kernel)
-            bool same = true;
-            for (int jj = 1; jj < gdirs; ++jj) {
-                long long dj = dir_begin + g * gdirs + jj;
-                if (dj > dir_end - 1) dj = dir_end - 1;
-                same = same && whole[dj * n_mics + mic] == whole[d * n_mics + mic];
-            }
-            entry |= same ? 1 : 0;
-        }
-        digest[i] = entry;
+        digest[i] = ((m * arrays * ncopies + (pd & (ncopies - 1))) * row_stride + lead - (pd & ~(ncopies - 1))) * 4;
         if (frac != nullptr) reinterpret_cast<float*>(digest)[h_off + i] = frac[d * n_mics + mic];
         if (reload_count != nullptr && j > 0) {
             // how often the sweep will have to re-read: this direction's delay differs from the previous direction's
@@ -851,6 +839,15 @@ __device__ __forceinline__ void issue_quads(Quad (&S)[NSEG], Quad (&D)[NSEG], in
                      : [e] "s"(e), [lb] "v"(lbase), [doff] "s"(d_off));
     }
 }
+// One segment, lerp, compile-time row stride: the difference quads sit DOFF bytes after the sample quads -- one address.
+template <int DOFF>
+__device__ __forceinline__ void issue_quads_i(Quad (&S)[1], Quad (&D)[1], int e, int lbase)
+{
+    int ad;
+    asm volatile("v_add_u32 %[ad], %[e], %[lb]\n\t" BF_RD(0, 0, 8)
+                 "ds_read_b64 %[d0l], %[ad] offset:%[o0]\n\tds_read_b64 %[d0h], %[ad] offset:%[o1]\n\t"
+                 : BF_S_OPS(0), BF_D_OPS(0), [ad] "=&v"(ad) : [e] "s"(e), [lb] "v"(lbase), [o0] "n"(DOFF), [o1] "n"(DOFF + 8));
+}
 // "the quads requested by issue_quads have arrived" (also drains outstanding scalar loads: same counter).  The wait is
 // the compiler-visible builtin, so that the compiler knows every earlier scalar load has landed and does not insert a
 // second, badly placed wait before the first use of a table entry; the empty asm ties the quad registers to this point.
@@ -929,10 +926,16 @@ __device__ __forceinline__ void lerp_quad(f32x2 (&ac)[2], const Quad& q, const Q
     "ds_read_b64 %[sl], %[ad] offset:0\n\tds_read_b64 %[sh], %[ad] offset:8\n\t" \
     "ds_read_b64 %[dl], %[ad2] offset:0\n\tds_read_b64 %[dh], %[ad2] offset:8\n\t" \
     "s_waitcnt lgkmcnt(0)\n\ts_branch .Lb" #j "_%=\n"
+// (compile-time row stride: the difference copies sit at a fixed byte distance -- an immediate offset, no second address)
+#define BF_Q_LERP_RELOAD_I(j, ec)                                                \
+    ".Lr" #j "_%=:\n\tv_add_u32 %[ad], %[" #ec "], %[lb]\n\t"                    \
+    "ds_read_b64 %[sl], %[ad] offset:0\n\tds_read_b64 %[sh], %[ad] offset:8\n\t" \
+    "ds_read_b64 %[dl], %[ad] offset:%[o0]\n\tds_read_b64 %[dh], %[ad] offset:%[o1]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\ts_branch .Lb" #j "_%=\n"
 #define BF_Q_EVEN "op_sel_hi:[0,1,1]"
 #define BF_Q_ODD "op_sel:[1,0,0] op_sel_hi:[1,1,1]"
 #define BF_Q_ACC(j, i) [a##j##0] "+v"(acc[i][0][0]), [a##j##1] "+v"(acc[i][0][1])
-template <bool LERP, int H>
+template <bool LERP, int H, int DOFF>   // DOFF > 0: byte distance of the difference copies as a compile-time constant
 __device__ __forceinline__ void steps4(f32x2 (&acc)[8][1][2], Quad& S, Quad& D, int ep, int e0, int e1, int e2, int e3,
                                        unsigned long long hlo, unsigned long long hhi, int lbase, int d_off)
 {
@@ -950,7 +953,7 @@ __device__ __forceinline__ void steps4(f32x2 (&acc)[8][1][2], Quad& S, Quad& D, 
                      ".subsection 1\n" BF_Q_PAD_RELOAD(0, e0) BF_Q_PAD_RELOAD(1, e1) BF_Q_PAD_RELOAD(2, e2) BF_Q_PAD_RELOAD(3, e3) "\t.subsection 0"
                      : BF_Q_ACC(0, B), BF_Q_ACC(1, B + 1), BF_Q_ACC(2, B + 2), BF_Q_ACC(3, B + 3), [sl] "+v"(S.lo), [sh] "+v"(S.hi), [ad] "=&v"(ad)
                      : [ep] "s"(ep), [e0] "s"(e0), [e1] "s"(e1), [e2] "s"(e2), [e3] "s"(e3), [lb] "v"(lbase) : "scc");
-    } else if constexpr (H == 0) {
+    } else if constexpr (H == 0 && DOFF == 0) {
         asm volatile(BF_Q_LERP(0, h0, BF_Q_EVEN) BF_Q_CHECK(1, e0, e1) BF_Q_LERP(1, h0, BF_Q_ODD) BF_Q_CHECK(2, e1, e2) BF_Q_LERP(2, h1, BF_Q_EVEN)
                          BF_Q_CHECK(3, e2, e3) BF_Q_LERP(3, h1, BF_Q_ODD)
                      ".subsection 1\n" BF_Q_LERP_RELOAD(1, e1) BF_Q_LERP_RELOAD(2, e2) BF_Q_LERP_RELOAD(3, e3) "\t.subsection 0"
@@ -958,7 +961,15 @@ __device__ __forceinline__ void steps4(f32x2 (&acc)[8][1][2], Quad& S, Quad& D, 
                        [dh] "+v"(D.hi), [ad] "=&v"(ad), [ad2] "=&v"(ad2)
                      : [e0] "s"(e0), [e1] "s"(e1), [e2] "s"(e2), [e3] "s"(e3), [h0] "s"(hlo), [h1] "s"(hhi), [lb] "v"(lbase), [doff] "s"(d_off)
                      : "scc", "v124", "v125", "v126", "v127");
-    } else {
+    } else if constexpr (H == 0) {
+        asm volatile(BF_Q_LERP(0, h0, BF_Q_EVEN) BF_Q_CHECK(1, e0, e1) BF_Q_LERP(1, h0, BF_Q_ODD) BF_Q_CHECK(2, e1, e2) BF_Q_LERP(2, h1, BF_Q_EVEN)
+                         BF_Q_CHECK(3, e2, e3) BF_Q_LERP(3, h1, BF_Q_ODD)
+                     ".subsection 1\n" BF_Q_LERP_RELOAD_I(1, e1) BF_Q_LERP_RELOAD_I(2, e2) BF_Q_LERP_RELOAD_I(3, e3) "\t.subsection 0"
+                     : BF_Q_ACC(0, B), BF_Q_ACC(1, B + 1), BF_Q_ACC(2, B + 2), BF_Q_ACC(3, B + 3), [sl] "+v"(S.lo), [sh] "+v"(S.hi), [dl] "+v"(D.lo),
+                       [dh] "+v"(D.hi), [ad] "=&v"(ad)
+                     : [e0] "s"(e0), [e1] "s"(e1), [e2] "s"(e2), [e3] "s"(e3), [h0] "s"(hlo), [h1] "s"(hhi), [lb] "v"(lbase), [o0] "n"(DOFF), [o1] "n"(DOFF + 8)
+                     : "scc", "v124", "v125", "v126", "v127");
+    } else if constexpr (DOFF == 0) {
         asm volatile(BF_Q_CHECK(0, ep, e0) BF_Q_LERP(0, h0, BF_Q_EVEN) BF_Q_CHECK(1, e0, e1) BF_Q_LERP(1, h0, BF_Q_ODD) BF_Q_CHECK(2, e1, e2)
                          BF_Q_LERP(2, h1, BF_Q_EVEN) BF_Q_CHECK(3, e2, e3) BF_Q_LERP(3, h1, BF_Q_ODD)
                      ".subsection 1\n" BF_Q_LERP_RELOAD(0, e0) BF_Q_LERP_RELOAD(1, e1) BF_Q_LERP_RELOAD(2, e2) BF_Q_LERP_RELOAD(3, e3) "\t.subsection 0"
@@ -966,6 +977,15 @@ __device__ __forceinline__ void steps4(f32x2 (&acc)[8][1][2], Quad& S, Quad& D, 
                        [dh] "+v"(D.hi), [ad] "=&v"(ad), [ad2] "=&v"(ad2)
                      : [ep] "s"(ep), [e0] "s"(e0), [e1] "s"(e1), [e2] "s"(e2), [e3] "s"(e3), [h0] "s"(hlo), [h1] "s"(hhi), [lb] "v"(lbase),
                        [doff] "s"(d_off)
+                     : "scc", "v124", "v125", "v126", "v127");
+    } else {
+        asm volatile(BF_Q_CHECK(0, ep, e0) BF_Q_LERP(0, h0, BF_Q_EVEN) BF_Q_CHECK(1, e0, e1) BF_Q_LERP(1, h0, BF_Q_ODD) BF_Q_CHECK(2, e1, e2)
+                         BF_Q_LERP(2, h1, BF_Q_EVEN) BF_Q_CHECK(3, e2, e3) BF_Q_LERP(3, h1, BF_Q_ODD)
+                     ".subsection 1\n" BF_Q_LERP_RELOAD_I(0, e0) BF_Q_LERP_RELOAD_I(1, e1) BF_Q_LERP_RELOAD_I(2, e2) BF_Q_LERP_RELOAD_I(3, e3) "\t.subsection 0"
+                     : BF_Q_ACC(0, B), BF_Q_ACC(1, B + 1), BF_Q_ACC(2, B + 2), BF_Q_ACC(3, B + 3), [sl] "+v"(S.lo), [sh] "+v"(S.hi), [dl] "+v"(D.lo),
+                       [dh] "+v"(D.hi), [ad] "=&v"(ad)
+                     : [ep] "s"(ep), [e0] "s"(e0), [e1] "s"(e1), [e2] "s"(e2), [e3] "s"(e3), [h0] "s"(hlo), [h1] "s"(hhi), [lb] "v"(lbase),
+                       [o0] "n"(DOFF), [o1] "n"(DOFF + 8)
                      : "scc", "v124", "v125", "v126", "v127");
     }
 }
@@ -1305,15 +1325,20 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
                 const int lb = 16 * lane + (int)(unsigned)(size_t)((__attribute__((address_space(3))) char*)lds);
                 const int d_off = 4 * C * rs;                   // D copies sit C rows after the s copies
                 constexpr bool kLerp = ALGO == ALGO_LERP;
+                constexpr int DOFF = (kLerp && NSEG == 1) ? 4 * C * RS : 0;   // ... a compile-time distance with the fixed row stride
                 struct Entries { int e[DW]; unsigned long long hp[DW / 2]; };   // offsets; lerp weights as (even, odd) direction pairs
+                // (et, ht): the table rows of the current six-mic trip's first mic; `m` counts from there, so that every request
+                // inside a trip is an immediate offset off the same two pointers
+                const int32_t* __restrict__ et = eg;
+                const float* __restrict__ ht = hg;
                 auto request = [&](Entries& t, int m) {
                     // (reads past the chunk's last mic stay inside the slack-padded table and are dropped)
 #pragma unroll
-                    for (int j = 0; j < DW; ++j) t.e[j] = eg[m * DW + j];
+                    for (int j = 0; j < DW; ++j) t.e[j] = et[m * DW + j];
 #pragma unroll
                     for (int j = 0; j < DW / 2; ++j) {
                         t.hp[j] = 0;
-                        if constexpr (kLerp) t.hp[j] = *reinterpret_cast<const unsigned long long*>(hg + m * DW + 2 * j);   // 8-byte aligned: DW is even
+                        if constexpr (kLerp) t.hp[j] = *reinterpret_cast<const unsigned long long*>(ht + m * DW + 2 * j);   // 8-byte aligned: DW is even
                     }
                 };
                 // A three-stage pipeline over the mics, so that no wave ever sits on an LDS or scalar-load round trip:
@@ -1333,27 +1358,30 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
                     for (int sg = 0; sg < NSEG; ++sg) S[q][sg].lo = S[q][sg].hi = Dq[q][sg].lo = Dq[q][sg].hi = f32x2{0.0f, 0.0f};
                 request(E[0], 0);
                 request(E[1], 1);
-                if constexpr (kPipe) issue_quads<NSEG, kLerp>(S[0], Dq[0], E[0].e[0] & ~7, lb, d_off);
+                auto issue = [&](Quad (&sq)[NSEG], Quad (&dq)[NSEG], int e) {
+                    if constexpr (DOFF > 0) issue_quads_i<DOFF>(sq, dq, e, lb);
+                    else issue_quads<NSEG, kLerp>(sq, dq, e, lb, d_off);
+                };
+                if constexpr (kPipe) issue(S[0], Dq[0], E[0].e[0]);
                 auto mic = [&](int m, auto pc, auto kc) {
                     constexpr int P = kPipe ? decltype(pc)::value : 0, K = decltype(kc)::value, K1 = (K + 1) % 3, K2 = (K + 2) % 3;
                     const Entries& cur = E[K];
                     if constexpr (kPipe) {
                         await_quads<NSEG>(S[P], Dq[P]);
-                        issue_quads<NSEG, kLerp>(S[P ^ 1], Dq[P ^ 1], E[K1].e[0] & ~7, lb, d_off);
+                        issue(S[P ^ 1], Dq[P ^ 1], E[K1].e[0]);
                         request(E[K2], m + 2);
                     } else {
                         request(E[K2], m + 2);
-                        reload_quads<NSEG, kLerp>(S[P], Dq[P], cur.e[0] & ~7, -1, lb, d_off);   // offsets are >= 0: -1 always loads (and waits)
+                        reload_quads<NSEG, kLerp>(S[P], Dq[P], cur.e[0], -1, lb, d_off);   // offsets are >= 0: -1 always loads (and waits)
                     }
                     if constexpr (NSEG == 1) {
                         static_assert(DW == 8, "two statements of four direction steps");
-                        const int e0 = cur.e[0] & ~7;
-                        steps4<kLerp, 0>(acc, S[P][0], Dq[P][0], e0, e0, cur.e[1], cur.e[2], cur.e[3], cur.hp[0], cur.hp[1], lb, d_off);
-                        steps4<kLerp, 1>(acc, S[P][0], Dq[P][0], cur.e[3], cur.e[4], cur.e[5], cur.e[6], cur.e[7], cur.hp[2], cur.hp[3], lb, d_off);
+                        steps4<kLerp, 0, DOFF>(acc, S[P][0], Dq[P][0], cur.e[0], cur.e[0], cur.e[1], cur.e[2], cur.e[3], cur.hp[0], cur.hp[1], lb, d_off);
+                        steps4<kLerp, 1, DOFF>(acc, S[P][0], Dq[P][0], cur.e[3], cur.e[4], cur.e[5], cur.e[6], cur.e[7], cur.hp[2], cur.hp[3], lb, d_off);
                     } else {
                         auto stepj = [&](auto jc) {
                             constexpr int j = decltype(jc)::value;
-                            if constexpr (j > 0) reload_quads<NSEG, kLerp>(S[P], Dq[P], cur.e[j], j == 1 ? (cur.e[0] & ~7) : cur.e[j - 1], lb, d_off);
+                            if constexpr (j > 0) reload_quads<NSEG, kLerp>(S[P], Dq[P], cur.e[j], j == 1 ? cur.e[0] : cur.e[j - 1], lb, d_off);
 #pragma unroll
                             for (int sg = 0; sg < NSEG; ++sg) {
                                 if constexpr (ALGO == ALGO_PAD) add_quad(acc[j][sg], S[P][sg]);
@@ -1373,13 +1401,41 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
                     }
                 };
                 using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-                for (int m = 0; m < mcc; m += 6) {             // (plain ifs, no early exit: keeps the register state of all paths identical)
-                    mic(m, I0{}, I0{});
-                    if (m + 1 < mcc) mic(m + 1, I1{}, I1{});
-                    if (m + 2 < mcc) mic(m + 2, I0{}, I2{});
-                    if (m + 3 < mcc) mic(m + 3, I1{}, I0{});
-                    if (m + 4 < mcc) mic(m + 4, I0{}, I1{});
-                    if (m + 5 < mcc) mic(m + 5, I1{}, I2{});
+                // The planner's usual chunk sizes get the mic count at compile time: whole six-mic trips without the per-mic
+                // "is there another mic" tests, table addresses as immediates off one pointer per trip.
+                auto trips = [&](auto mcc_c) {
+                    constexpr int MCC = decltype(mcc_c)::value;
+                    if constexpr (MCC > 0) {
+                        constexpr int R0 = MCC / 6 * 6;
+#pragma unroll 1
+                        for (int m = 0; m < R0; m += 6) {
+                            mic(0, I0{}, I0{}); mic(1, I1{}, I1{}); mic(2, I0{}, I2{});
+                            mic(3, I1{}, I0{}); mic(4, I0{}, I1{}); mic(5, I1{}, I2{});
+                            et += 6 * DW; ht += 6 * DW;
+                        }
+                        if constexpr (MCC - R0 > 0) mic(0, I0{}, I0{});
+                        if constexpr (MCC - R0 > 1) mic(1, I1{}, I1{});
+                        if constexpr (MCC - R0 > 2) mic(2, I0{}, I2{});
+                        if constexpr (MCC - R0 > 3) mic(3, I1{}, I0{});
+                        if constexpr (MCC - R0 > 4) mic(4, I0{}, I1{});
+                    } else {
+                        for (int m = 0; m < mcc; m += 6) {     // (plain ifs, no early exit: keeps the register state of all paths identical)
+                            mic(0, I0{}, I0{});
+                            if (m + 1 < mcc) mic(1, I1{}, I1{});
+                            if (m + 2 < mcc) mic(2, I0{}, I2{});
+                            if (m + 3 < mcc) mic(3, I1{}, I0{});
+                            if (m + 4 < mcc) mic(4, I0{}, I1{});
+                            if (m + 5 < mcc) mic(5, I1{}, I2{});
+                            et += 6 * DW; ht += 6 * DW;
+                        }
+                    }
+                };
+                if constexpr (NSEG == 1) {
+                    if (mcc == 32) trips(std::integral_constant<int, 32>{});
+                    else if (mcc == 16) trips(std::integral_constant<int, 16>{});
+                    else trips(I0{});
+                } else {
+                    trips(I0{});
                 }
                 // nothing may stay in flight into registers the compiler is about to reuse
                 await_quads<NSEG>(S[0], Dq[0]);
