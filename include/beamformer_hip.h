@@ -105,7 +105,8 @@ void bf_clear_error(void);
  * loading the library). */
 int bf_gpu_available(void);
 /* Kernel family of the last delay-and-sum launch: 0 strided, 1 quad + DPP, 2 shifted copies (sweep), 3 shifted copies
- * (direction-outer, chosen for tables without structure), 4 shifted copies (8-tap FIR); -1 before the first launch. */
+ * (direction-outer, chosen for tables without structure), 4 shifted copies (8-tap FIR), 5 shifted copies (sweep, two
+ * frames per workgroup: batched launches of pad / lerp); -1 before the first launch. */
 int bf_last_das_variant(void);
 /* Select the HIP device (default 0, or $BF_DEVICE) before the first load_* call. */
 int bf_set_device(int device);

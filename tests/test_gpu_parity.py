@@ -275,7 +275,7 @@ def test_batched_device_path(nat, algo):
     assert nat.lib.bf_das_device(ALGOS[algo], d_sig.data_ptr(), M, d_img.data_ptr(), D, F, nat.iptr(mics), M, 0, D, stream) == 0
     torch.cuda.synchronize()
     assert np.array_equal(d_img.cpu().numpy(), ref_imgs)
-    assert nat.lib.bf_last_das_variant() == 2          # geometric tables: the sweep with shared reads
+    assert nat.lib.bf_last_das_variant() == 5          # geometric tables, a batch: the sweep with shared reads, two frames per workgroup
     # two direction shards, as two ranks would compute them
     cut = 5003
     lo = torch.full((F, cut), float("nan"), dtype=torch.float32, device="cuda")
@@ -284,6 +284,36 @@ def test_batched_device_path(nat, algo):
     assert nat.lib.bf_das_device(ALGOS[algo], d_sig.data_ptr(), M, hi.data_ptr(), D - cut, F, nat.iptr(mics), M, cut, D, stream) == 0
     torch.cuda.synchronize()
     assert np.array_equal(torch.cat([lo, hi], dim=1).cpu().numpy(), ref_imgs)
+
+
+@pytest.mark.parametrize("n_active,F", [(64, 5), (64, 2), (32, 3)])
+@pytest.mark.parametrize("algo", ["pad", "lerp"])
+def test_batched_frame_pairs(nat, oracle_lib, algo, n_active, F):
+    """The two-frames-per-workgroup kernel: odd frame counts (the last workgroup row owns a single frame), a subset of the
+    microphone rows (adaptive_array): bit-identical to the CPU oracle, frame by frame, and to the one-frame kernel."""
+    torch = _torch()
+    import synth
+    cfg = "cfg2"
+    c = util.configure(cfg)
+    M, N, X, Y = c["M"], c["N"], c["X"], c["Y"]
+    D = X * Y
+    frames = synth.frame_batch(M, N, F)
+    mics = (np.arange(n_active) * (M // n_active)).astype(np.int32)     # rows of the frame the active slots read
+    table = np.ascontiguousarray(np.asarray(util.table_for(algo, cfg)).reshape(X, Y, M)[..., :n_active])
+    orc = oracle_lib.Oracle(N, X, Y, 8)
+    orc.load(ALGOS[algo], table)
+    one = run_product(nat, algo, table, frames[F - 1], mics)   # loads the table; one frame: the one-frame kernel
+    assert nat.lib.bf_last_das_variant() == 2
+    d_sig = torch.from_numpy(frames).cuda()
+    d_img = torch.full((F, D), float("nan"), dtype=torch.float32, device="cuda")
+    assert nat.lib.bf_das_device(ALGOS[algo], d_sig.data_ptr(), M, d_img.data_ptr(), D, F, nat.iptr(mics), n_active, 0, D,
+                                 torch.cuda.current_stream().cuda_stream) == 0, nat.check()
+    torch.cuda.synchronize()
+    assert nat.lib.bf_last_das_variant() == 5
+    got = d_img.cpu().numpy()
+    assert np.array_equal(got[F - 1], one.reshape(-1))
+    for f in range(F):
+        assert np.array_equal(got[f], orc.mimo_range(ALGOS[algo], frames[f], mics, 0, D).reshape(-1)), f
 
 
 def test_full_size_properties(nat):

@@ -50,11 +50,11 @@ struct DevBuf {
 // Everything a digest (bf::launch_digest) depends on; compared field by field.
 struct DigestKey {
     bool valid = false;
-    int mic_chunk = 0, row_stride = 0, lead = 0, algo = 0, dpw = 0, dir_begin = 0, dir_end = 0, n_mics = 0;
+    int mic_chunk = 0, row_stride = 0, lead = 0, algo = 0, dpw = 0, dir_begin = 0, dir_end = 0, n_mics = 0, nf = 0;
     bool operator==(const DigestKey& o) const
     {
         return valid && o.valid && mic_chunk == o.mic_chunk && row_stride == o.row_stride && lead == o.lead && algo == o.algo && dpw == o.dpw &&
-               dir_begin == o.dir_begin && dir_end == o.dir_end && n_mics == o.n_mics;
+               dir_begin == o.dir_begin && dir_end == o.dir_end && n_mics == o.n_mics && nf == o.nf;
     }
 };
 
@@ -315,7 +315,7 @@ bool ensure_digest(TableSet& t, bf::DasLaunch& L, bf::DasPlan& plan, hipStream_t
     S().last_variant = plan.layout == 2 ? 4 : plan.layout;          // refined below for the digest-driven kernels
     if (plan.layout != 2 || L.algo == bf::ALGO_FIR_NAIVE || L.algo == bf::ALGO_FIR_VEC) return true;   // the plain FIRs have no whole-sample table
     // everything the digest depends on: the plan's geometry, the algorithm and (grouped layouts) the direction range
-    const DigestKey key{true, plan.mic_chunk, plan.row_stride, plan.lead, L.algo, plan.dpw, L.dir_begin, L.dir_end, L.n_mics};
+    const DigestKey key{true, plan.mic_chunk, plan.row_stride, plan.lead, L.algo, plan.dpw, L.dir_begin, L.dir_end, L.n_mics, plan.nf};
     if (!(t.digest_key == key) || !t.digest.p) {
         State& s = S();
         if (!HIP_OK(t.digest.reserve(bf::digest_elements(L, plan))) || !HIP_OK(s.d_counter.reserve(1))) return false;
@@ -345,7 +345,7 @@ bool ensure_digest(TableSet& t, bf::DasLaunch& L, bf::DasPlan& plan, hipStream_t
     }
     L.tab.digest_direct = t.digest_direct;
     L.tab.digest = t.digest.p;
-    S().last_variant = (L.algo == bf::ALGO_PAD || L.algo == bf::ALGO_LERP) ? (t.digest_direct ? 3 : 2) : 4;
+    S().last_variant = (L.algo == bf::ALGO_PAD || L.algo == bf::ALGO_LERP) ? (t.digest_direct ? 3 : plan.nf == 2 ? 5 : 2) : 4;
     return true;
 }
 

@@ -60,6 +60,7 @@ struct DasPlan {
     int quad;        // 1: lane owns 4 consecutive samples (ds_read_b128 + DPP), 0: lane-strided samples (ds_read_b32)
     int layout;      // 0 strided, 1 quad + DPP, 2 shifted copies (pad / lerp, N <= 256)
     int dpw;         // directions a wave carries across mic chunks
+    int nf;          // frames a workgroup carries (2: das_pair_kernel -- pad / lerp at N <= 256 with the fixed row stride, a multiple of 16 mics and two or more frames)
     int copies;      // layout 2: shifted copies per staged array (2: the sweep of pad / lerp, 4: FIR flavours and the DIRECT variant)
     int tile_dirs;   // directions per workgroup
     int n_tiles;     // padded to a multiple of 8 (XCD affinity: tile % 8 == workgroup id % 8)

@@ -43,6 +43,7 @@ struct KArgs {
     int n_is_pow2;
     float inv_n;
     int debug;   // profiling only (BF_DEBUG): bit 0 = skip the ordered power sum (wrong images)
+    int n_frames;   // frames of the launch (das_pair_kernel: whether a workgroup's second frame exists)
     long long digest_h_off;   // shifted-copies pad / lerp: where the grouped lerp weights start in the digest buffer (floats)
 };
 
@@ -1512,6 +1513,281 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
     }
 }
 
+
+// ==================================================================================================
+// Two frames per workgroup (pad / lerp, N <= 256, fixed row stride, mic count a multiple of 16, two or more frames).
+//
+// The sweep above is bound by the number of instructions a SIMD issues, and per (direction, mic) step only 2 (pad) / 4
+// (lerp) of them are arithmetic: the rest -- table loads, the address, the offset tests, waits -- depends on the tables
+// alone.  A wave that carries its eight directions through TWO frames pays that part once per 4 / 8 packed operations.
+// Same layout as das_copies_kernel<.., NSEG = 1, RS = kRs, W = 16> (two shifted copies, difference rows for lerp), with the
+// two frames' rows of a mic next to each other: frame 1's quads sit kFoff bytes after frame 0's, an immediate offset off the
+// same address.  16 mics x 2 frames per chunk; the 64 accumulator registers leave no room for quads in flight across a
+// mic, so a mic's first quads are read (and waited for) in place -- the other three waves of the SIMD cover that.
+// Mic order and operation order per frame are those of the one-frame kernel: bit-identical maps.
+template <int ALGO>
+struct PairGeo {
+    static constexpr bool kLerp = ALGO == ALGO_LERP;
+    static constexpr int kA = kLerp ? 2 : 1, kC = 2, kRs = Geo<1>::kRs, kLead = Geo<1>::kLead, kMc = 16;
+    static constexpr int kSlot = kA * kC * kRs;          // floats per staged (mic, frame)
+    static constexpr int kFoff = kSlot * 4;              // bytes from a frame-0 quad to the same quad of frame 1
+    static constexpr int kDoff = kC * kRs * 4;           // bytes from a sample quad to its difference quad
+    static constexpr size_t kLds = (size_t)kMc * 2 * kSlot * 4 > (size_t)128 * Geo<1>::kPark * 4 ? (size_t)kMc * 2 * kSlot * 4 : (size_t)128 * Geo<1>::kPark * 4;
+};
+
+#define BF_P_ACC(n, j, f) [a##n##0] "+v"(acc[j][f][0]), [a##n##1] "+v"(acc[j][f][1])
+// pad: two direction steps x two frames; a0/a1 = step A frame 0/1, a2/a3 = step B frame 0/1
+#define BF_P_PAD_STEP(n0, n1)                                                                             \
+    "v_pk_add_f32 %[a" #n0 "0], %[a" #n0 "0], %[s0l]\n\tv_pk_add_f32 %[a" #n0 "1], %[a" #n0 "1], %[s0h]\n\t" \
+    "v_pk_add_f32 %[a" #n1 "0], %[a" #n1 "0], %[s1l]\n\tv_pk_add_f32 %[a" #n1 "1], %[a" #n1 "1], %[s1h]\n\t"
+#define BF_P_PAD_READ                                                                                     \
+    "ds_read_b64 %[s0l], %[ad] offset:0\n\tds_read_b64 %[s0h], %[ad] offset:8\n\t"                         \
+    "ds_read_b64 %[s1l], %[ad] offset:%[f0]\n\tds_read_b64 %[s1h], %[ad] offset:%[f8]\n\t"                 \
+    "s_waitcnt lgkmcnt(0)\n\t"
+// lerp: frame 0's products through v[120:123], frame 1's through v[124:127] (clobbers), so that each add is four
+// instructions behind its product
+#define BF_P_LERP_STEP(n0, n1, mods)                                                                      \
+    "v_pk_fma_f32 v[120:121], %[h], %[d0l], %[s0l] " mods "\n\tv_pk_fma_f32 v[122:123], %[h], %[d0h], %[s0h] " mods "\n\t" \
+    "v_pk_fma_f32 v[124:125], %[h], %[d1l], %[s1l] " mods "\n\tv_pk_fma_f32 v[126:127], %[h], %[d1h], %[s1h] " mods "\n\t" \
+    "v_pk_add_f32 %[a" #n0 "0], %[a" #n0 "0], v[120:121]\n\tv_pk_add_f32 %[a" #n0 "1], %[a" #n0 "1], v[122:123]\n\t"         \
+    "v_pk_add_f32 %[a" #n1 "0], %[a" #n1 "0], v[124:125]\n\tv_pk_add_f32 %[a" #n1 "1], %[a" #n1 "1], v[126:127]\n\t"
+#define BF_P_LERP_READ                                                                                    \
+    "ds_read_b64 %[s0l], %[ad] offset:0\n\tds_read_b64 %[s0h], %[ad] offset:8\n\t"                         \
+    "ds_read_b64 %[d0l], %[ad] offset:%[g0]\n\tds_read_b64 %[d0h], %[ad] offset:%[g8]\n\t"                 \
+    "ds_read_b64 %[s1l], %[ad] offset:%[f0]\n\tds_read_b64 %[s1h], %[ad] offset:%[f8]\n\t"                 \
+    "ds_read_b64 %[d1l], %[ad] offset:%[k0]\n\tds_read_b64 %[d1h], %[ad] offset:%[k8]\n\t"                 \
+    "s_waitcnt lgkmcnt(0)\n\t"
+#define BF_P_ADDR(e) "v_add_u32 %[ad], %[" #e "], %[lb]\n\t"
+#define BF_P_CHECK(n, ep, ec) "s_cmp_lg_u32 %[" #ec "], %[" #ep "]\n\ts_cbranch_scc1 .Lr" #n "_%=\n.Lb" #n "_%=:\n\t"
+#define BF_P_STUB(n, ec, READ) ".Lr" #n "_%=:\n\t" BF_P_ADDR(ec) READ "s_branch .Lb" #n "_%=\n"
+
+// Direction steps 2 Q and 2 Q + 1 of a mic for both frames.  Q = 0 reads the mic's first quads in place (offset eb; ea is
+// unused) before step 0; the others test ea -> eb before their first step; all test eb -> ec before their second.
+template <int ALGO, int Q>
+__device__ __forceinline__ void pair_steps(f32x2 (&acc)[8][2][2], Quad& S0, Quad& D0, Quad& S1, Quad& D1, int ea, int eb, int ec,
+                                           unsigned long long h, int lbase)
+{
+    using G = PairGeo<ALGO>;
+    constexpr int JA = 2 * Q, JB = 2 * Q + 1;
+    int ad;
+    if constexpr (ALGO == ALGO_PAD) {
+        // pad_and_sum.c:41-47   out[k] += s[k - p]
+        if constexpr (Q == 0) {
+            asm volatile(BF_P_ADDR(eb) BF_P_PAD_READ BF_P_PAD_STEP(0, 1) BF_P_CHECK(1, eb, ec) BF_P_PAD_STEP(2, 3)
+                         ".subsection 1\n" BF_P_STUB(1, ec, BF_P_PAD_READ) "\t.subsection 0"
+                         : BF_P_ACC(0, JA, 0), BF_P_ACC(1, JA, 1), BF_P_ACC(2, JB, 0), BF_P_ACC(3, JB, 1), [s0l] "+v"(S0.lo), [s0h] "+v"(S0.hi),
+                           [s1l] "+v"(S1.lo), [s1h] "+v"(S1.hi), [ad] "=&v"(ad)
+                         : [eb] "s"(eb), [ec] "s"(ec), [lb] "v"(lbase), [f0] "n"(G::kFoff), [f8] "n"(G::kFoff + 8) : "scc");
+        } else {
+            asm volatile(BF_P_CHECK(0, ea, eb) BF_P_PAD_STEP(0, 1) BF_P_CHECK(1, eb, ec) BF_P_PAD_STEP(2, 3)
+                         ".subsection 1\n" BF_P_STUB(0, eb, BF_P_PAD_READ) BF_P_STUB(1, ec, BF_P_PAD_READ) "\t.subsection 0"
+                         : BF_P_ACC(0, JA, 0), BF_P_ACC(1, JA, 1), BF_P_ACC(2, JB, 0), BF_P_ACC(3, JB, 1), [s0l] "+v"(S0.lo), [s0h] "+v"(S0.hi),
+                           [s1l] "+v"(S1.lo), [s1h] "+v"(S1.hi), [ad] "=&v"(ad)
+                         : [ea] "s"(ea), [eb] "s"(eb), [ec] "s"(ec), [lb] "v"(lbase), [f0] "n"(G::kFoff), [f8] "n"(G::kFoff + 8) : "scc");
+        }
+    } else {
+        // lerp_and_sum.c:50-56  out[k] += s[i] + h * (s[i+1] - s[i]),  i = k - p - 1   (gcc contracts it into one fma)
+#define BF_P_LERP_OUTS                                                                                                         \
+        BF_P_ACC(0, JA, 0), BF_P_ACC(1, JA, 1), BF_P_ACC(2, JB, 0), BF_P_ACC(3, JB, 1), [s0l] "+v"(S0.lo), [s0h] "+v"(S0.hi),    \
+        [d0l] "+v"(D0.lo), [d0h] "+v"(D0.hi), [s1l] "+v"(S1.lo), [s1h] "+v"(S1.hi), [d1l] "+v"(D1.lo), [d1h] "+v"(D1.hi), [ad] "=&v"(ad)
+#define BF_P_LERP_IMMS                                                                                                         \
+        [g0] "n"(G::kDoff), [g8] "n"(G::kDoff + 8), [f0] "n"(G::kFoff), [f8] "n"(G::kFoff + 8), [k0] "n"(G::kFoff + G::kDoff),   \
+        [k8] "n"(G::kFoff + G::kDoff + 8)
+        if constexpr (Q == 0) {
+            asm volatile(BF_P_ADDR(eb) BF_P_LERP_READ BF_P_LERP_STEP(0, 1, "op_sel_hi:[0,1,1]") BF_P_CHECK(1, eb, ec)
+                         BF_P_LERP_STEP(2, 3, "op_sel:[1,0,0] op_sel_hi:[1,1,1]")
+                         ".subsection 1\n" BF_P_STUB(1, ec, BF_P_LERP_READ) "\t.subsection 0"
+                         : BF_P_LERP_OUTS
+                         : [eb] "s"(eb), [ec] "s"(ec), [h] "s"(h), [lb] "v"(lbase), BF_P_LERP_IMMS
+                         : "scc", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+        } else {
+            asm volatile(BF_P_CHECK(0, ea, eb) BF_P_LERP_STEP(0, 1, "op_sel_hi:[0,1,1]") BF_P_CHECK(1, eb, ec)
+                         BF_P_LERP_STEP(2, 3, "op_sel:[1,0,0] op_sel_hi:[1,1,1]")
+                         ".subsection 1\n" BF_P_STUB(0, eb, BF_P_LERP_READ) BF_P_STUB(1, ec, BF_P_LERP_READ) "\t.subsection 0"
+                         : BF_P_LERP_OUTS
+                         : [ea] "s"(ea), [eb] "s"(eb), [ec] "s"(ec), [h] "s"(h), [lb] "v"(lbase), BF_P_LERP_IMMS
+                         : "scc", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+        }
+#undef BF_P_LERP_OUTS
+#undef BF_P_LERP_IMMS
+    }
+}
+
+template <int ALGO>
+__global__ void __launch_bounds__(1024, 4) das_pair_kernel(BF_TABLE_PARAMS, KArgs a)
+{
+    using G = PairGeo<ALGO>;
+    constexpr bool kLerp = G::kLerp;
+    constexpr int A = G::kA, C = G::kC, RS = G::kRs, LEAD = G::kLead, MC = G::kMc, W = 16, DW = 8, kGroup = DW * W, kPark = Geo<1>::kPark;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tile = (int)(blockIdx.x % (unsigned)a.n_tiles);
+    const int f0 = 2 * (int)(blockIdx.x / (unsigned)a.n_tiles);
+    const bool two = f0 + 1 < a.n_frames;                      // an odd frame count: the last workgroup row computes its frame twice
+    const int f1 = two ? f0 + 1 : f0;
+    const int tile_begin = a.dir_begin + tile * a.tile_dirs;
+    if (tile_begin >= a.dir_end) return;
+    const int tile_end = min(tile_begin + a.tile_dirs, a.dir_end);
+    const int M = a.n_mics, N = a.n_samples;                   // M % 16 == 0, N % 4 == 0, N <= 256 (plan_das)
+    const float* __restrict__ sig0 = signals + (size_t)f0 * a.m_total * N;
+    const float* __restrict__ sig1 = signals + (size_t)f1 * a.m_total * N;
+    float* __restrict__ img0 = images + (size_t)f0 * a.image_stride;
+    float* __restrict__ img1 = images + (size_t)f1 * a.image_stride;
+    const int32_t* __restrict__ dig = reinterpret_cast<const int32_t*>(taps);   // the digest rides in the unused `taps` slot
+
+    // This wave stages the (mic, frame) pairs pr = wave + 16 i, i = 0, 1  <->  chunk mic pr >> 1, frame pr & 1.
+    // Lane c holds chunk c's mic id (first 64 chunks): the per-chunk prefetch is then one independent load.
+    int vmic[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int cm = (wave + W * i) >> 1;
+        vmic[i] = (lane < a.n_chunks) ? mics[lane * MC + cm] : 0;
+    }
+    auto fetch = [&](int ch, float4 (&st)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pr = wave + W * i, cm = pr >> 1;
+            const int mic = (ch < kWave) ? __builtin_amdgcn_readlane(vmic[i], ch) : mics[ch * MC + cm];
+            const float* src = ((pr & 1) ? sig1 : sig0) + (size_t)mic * N;
+            st[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (4 * lane < N) st[i] = *reinterpret_cast<const float4*>(src + 4 * lane);
+        }
+    };
+    auto stage = [&](const float4 (&st)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pr = wave + W * i;
+            float* row0 = lds + pr * G::kSlot;                 // (cm * 2 + frame) * kSlot
+            const float4 v = st[i];
+            const float py = dpp_prev(v.y), pz = dpp_prev(v.z), pw = dpp_prev(v.w), nx = dpp_next(v.x);
+            write_copies<C>(row0, RS, LEAD, lane, v, py, pz, pw);
+            if constexpr (kLerp) {
+                // D[i] = s[i+1] - s[i], the reference's own subtraction (lerp_and_sum.c:54); D[-1] stays 0 (prefix)
+                const float4 dq = make_float4(v.y - v.x, v.z - v.y, v.w - v.z, nx - v.w);
+                const float dy = dpp_prev(dq.y), dz = dpp_prev(dq.z), dw = dpp_prev(dq.w);
+                write_copies<C>(row0 + C * RS, RS, LEAD, lane, dq, dy, dz, dw);
+            }
+            if (lane < (LEAD >> 2)) {                         // the zero prefix (also wiped by the parked rows of the previous group)
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int c = 0; c < C * A; ++c) reinterpret_cast<float4*>(row0 + c * RS)[lane] = z;
+            }
+        }
+    };
+
+    float4 staged[2];
+    fetch(0, staged);
+    const int lb = 16 * lane + (int)(unsigned)(size_t)((__attribute__((address_space(3))) char*)lds);
+
+    for (int g0 = tile_begin; g0 < tile_end; g0 += kGroup) {
+        f32x2 acc[DW][2][2];
+#pragma unroll
+        for (int j = 0; j < DW; ++j)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) { acc[j][f][0] = f32x2{0.0f, 0.0f}; acc[j][f][1] = f32x2{0.0f, 0.0f}; }
+
+        for (int ch = 0; ch < a.n_chunks; ++ch) {
+            __syncthreads();   // every wave is done with the previous contents (chunk reads or parked rows)
+            stage(staged);
+            __syncthreads();
+            {   // request the next chunk (or the next group's first) while this one is consumed
+                int ng0 = g0, nch = ch + 1;
+                if (nch == a.n_chunks) { nch = 0; ng0 = g0 + kGroup; }
+                if (ng0 < tile_end) fetch(nch, staged);
+            }
+            const int dw0 = g0 + wave * DW;                     // wave-uniform
+            if (dw0 < tile_end) {
+                const size_t grp = (size_t)(dw0 - a.dir_begin) / DW;
+                const int32_t* __restrict__ et = dig + (grp * M + (size_t)ch * MC) * DW;
+                const float* __restrict__ ht = reinterpret_cast<const float*>(dig) + a.digest_h_off + (grp * M + (size_t)ch * MC) * DW;
+                struct Entries { int e[DW]; unsigned long long hp[DW / 2]; };
+                auto request = [&](Entries& t, int m) {
+                    // (reads past the chunk's last mic stay inside the slack-padded table and are dropped)
+#pragma unroll
+                    for (int j = 0; j < DW; ++j) t.e[j] = et[m * DW + j];
+#pragma unroll
+                    for (int j = 0; j < DW / 2; ++j) {
+                        t.hp[j] = 0;
+                        if constexpr (kLerp) t.hp[j] = *reinterpret_cast<const unsigned long long*>(ht + m * DW + 2 * j);
+                    }
+                };
+                Entries E[3];
+                Quad S0, D0, S1, D1;
+                S0.lo = S0.hi = D0.lo = D0.hi = S1.lo = S1.hi = D1.lo = D1.hi = f32x2{0.0f, 0.0f};
+                request(E[0], 0);
+                request(E[1], 1);
+                auto mic = [&](int m, auto kc) {
+                    constexpr int K = decltype(kc)::value, K2 = (K + 2) % 3;
+                    const Entries& cur = E[K];
+                    pair_steps<ALGO, 0>(acc, S0, D0, S1, D1, cur.e[0], cur.e[0], cur.e[1], cur.hp[0], lb);
+                    request(E[K2], m + 2);      // after the first statement's wait, so that it does not sit on these loads
+                    pair_steps<ALGO, 1>(acc, S0, D0, S1, D1, cur.e[1], cur.e[2], cur.e[3], cur.hp[1], lb);
+                    pair_steps<ALGO, 2>(acc, S0, D0, S1, D1, cur.e[3], cur.e[4], cur.e[5], cur.hp[2], lb);
+                    pair_steps<ALGO, 3>(acc, S0, D0, S1, D1, cur.e[5], cur.e[6], cur.e[7], cur.hp[3], lb);
+                };
+                using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+#pragma unroll 1
+                for (int t = 0; t < MC / 3; ++t) {             // 16 mics: five trips of three and one more
+                    mic(0, I0{}); mic(1, I1{}); mic(2, I2{});
+                    et += 3 * DW; ht += 3 * DW;
+                }
+                mic(0, I0{});
+            }
+        }
+
+        // ---- k-ordered mean power (pad_and_sum.c:120-128), one frame at a time: the 16 waves park the squared means of their
+        // directions (row = direction; the rows alias the chunk buffer), then one direction per lane runs the sequential sum.
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            __syncthreads();
+            auto park = [&](auto mul_c) {
+#pragma unroll
+                for (int j = 0; j < DW; ++j) {
+                    float* row = lds + (wave * DW + j) * kPark;
+                    const f32x2 a0 = acc[j][f][0], a1 = acc[j][f][1];
+                    float o0, o1, o2, o3;
+                    if constexpr (decltype(mul_c)::value) {
+                        o0 = a0.x * a.inv_n; o1 = a0.y * a.inv_n; o2 = a1.x * a.inv_n; o3 = a1.y * a.inv_n;
+                    } else {
+                        float fm = (float)M;
+                        asm volatile("" : "+v"(fm));   // not speculatable: keeps this path behind its branch
+                        o0 = a0.x / fm; o1 = a0.y / fm; o2 = a1.x / fm; o3 = a1.y / fm;
+                    }
+                    reinterpret_cast<float4*>(row)[lane] = make_float4(o0 * o0, o1 * o1, o2 * o2, o3 * o3);
+                }
+            };
+            if (__builtin_expect(a.n_is_pow2, 1)) park(std::true_type{}); else park(std::false_type{});
+            __syncthreads();
+            const int g = wave * kWave + lane;            // parked row of this lane
+            const int d = g0 + g;
+            if (g < kGroup && d < tile_end && (f == 0 || two)) {
+                const float* row = lds + g * kPark;
+                const float4* row4 = reinterpret_cast<const float4*>(row);
+                float sum = 0.0f;
+                int k = 0;
+                for (; k + 32 <= N; k += 32) {
+                    float4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = row4[(k >> 2) + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { sum += v[u].x; sum += v[u].y; sum += v[u].z; sum += v[u].w; }
+                }
+                for (; k < N; ++k) sum += row[k];
+                (f == 0 ? img0 : img1)[d - a.image_origin] = sum / (float)N;
+            }
+        }
+    }
+}
+#undef BF_P_ACC
+#undef BF_P_PAD_STEP
+#undef BF_P_PAD_READ
+#undef BF_P_LERP_STEP
+#undef BF_P_LERP_READ
+#undef BF_P_ADDR
+#undef BF_P_CHECK
+#undef BF_P_STUB
+
 }  // namespace copies
 
 template <int ALGO, int NC>
@@ -1533,6 +1809,28 @@ hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, in
             if (kNeedsDigest && L.tab.digest == nullptr) return hipErrorInvalidValue;   // launch_digest first
             if (kFir && L.n_taps != 8) return hipErrorInvalidValue;
             constexpr int NSEG = NC / 4;
+            if constexpr (!kFir && NSEG == 1) {
+                if (plan.nf == 2) {
+                    if (L.tab.digest == nullptr || L.tab.digest_direct || plan.waves != copies::kWaves || plan.mic_chunk != copies::PairGeo<ALGO>::kMc ||
+                        plan.row_stride != copies::PairGeo<ALGO>::kRs || plan.lead != copies::PairGeo<ALGO>::kLead || (L.n_mics % 16) != 0)
+                        return hipErrorInvalidValue;
+                    auto kernel = copies::das_pair_kernel<ALGO>;
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
+                    if (e != hipSuccess) return e;
+                    static int pair_scratch = -1;             // (asm statements pass registers to each other: refuse a build that spills)
+                    if (pair_scratch < 0) {
+                        hipFuncAttributes fa{};
+                        e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel));
+                        if (e != hipSuccess) return e;
+                        pair_scratch = (int)fa.localSizeBytes;
+                    }
+                    if (pair_scratch != 0) return hipErrorInvalidDeviceFunction;
+                    const dim3 pair_grid((unsigned)plan.n_tiles * (unsigned)((frames + 1) / 2));
+                    hipLaunchKernelGGL(kernel, pair_grid, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole, L.tab.frac,
+                                       reinterpret_cast<const float*>(L.tab.digest), a);
+                    return hipGetLastError();
+                }
+            }
             using G = copies::Geo<NSEG>;
             constexpr int kRs = kFir ? G::kRsFir : G::kRs;
             const bool fixed = plan.row_stride == kRs && plan.lead == G::kLead;
@@ -1640,6 +1938,7 @@ KArgs make_args(const DasLaunch& L, const DasPlan& plan)
     a.n_is_pow2 = (L.n_mics & (L.n_mics - 1)) == 0;
     a.inv_n = 1.0f / (float)L.n_mics;
     a.debug = L.debug;
+    a.n_frames = L.frames;
     a.digest_h_off = (plan.layout == 2 && L.algo == ALGO_LERP) ? grouped_entries_for_args(L, plan) : 0;
     return a;
 }
@@ -1659,6 +1958,7 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
     if (L.n_mics < 1 || L.frames < 1 || L.dir_end <= L.dir_begin) return fail(4);
 
     DasPlan p{};
+    p.nf = 1;
     int nc = (L.n_samples + kWave - 1) / kWave;
     p.nc = nc <= 1 ? 1 : nc <= 2 ? 2 : nc <= 4 ? 4 : nc <= 8 ? 8 : 16;
     const int T = fir ? L.n_taps : 0;
@@ -1720,10 +2020,18 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
         mc = mc >= 32 ? 32 : mc >= 16 ? 16 : mc >= 8 ? 8 : mc >= 4 ? 4 : mc >= 2 ? 2 : mc;
         if (mc < 1) return fail(3);
         if (mc > L.n_mics) mc = L.n_mics;
+        // Two frames per workgroup (das_pair_kernel) where its fixed geometry applies: the per-step scalar work is then shared
+        // by both frames.  (debug bit 4: A/B switch)
+        p.nf = 1;
+        if (plain && nseg == 1 && waves == copies::kWaves && !L.tab.digest_direct && p.lead == fixed_lead && (L.n_mics % 16) == 0 &&
+            (L.n_samples % 4) == 0 && L.frames >= 2 && !(L.debug & 16)) {
+            p.nf = 2;
+            mc = 16;
+        }
         p.mic_chunk = mc; p.n_chunks = (L.n_mics + mc - 1) / mc;
         p.waves = waves; p.dpw = dw; p.srow = nseg * 256 + 4;
         p.scratch_off = 0;
-        const size_t buf = slot_bytes * (size_t)mc;
+        const size_t buf = slot_bytes * (size_t)mc * (size_t)p.nf;
         const size_t wave_rows = (size_t)dw * p.srow * sizeof(float);          // the parked rows of one wave
         p.lds_bytes = buf > 2 * wave_rows ? buf : 2 * wave_rows;
         if (nseg == 1 && p.lds_bytes < waves * wave_rows) p.lds_bytes = waves * wave_rows;   // N <= 256: the whole group parks at once
@@ -1742,9 +2050,10 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
     const int group = p.waves * p.dpw;
     const long long dirs = (long long)(L.dir_end - L.dir_begin);
     const long long target_wgs = (long long)n_cus * 4;
-    long long td = (dirs * L.frames + target_wgs - 1) / target_wgs;
-    if (dirs * L.frames < (long long)n_cus * group) {
-        td = (dirs * L.frames + n_cus - 1) / n_cus;
+    const long long wg_frames = p.nf == 2 ? (L.frames + 1) / 2 : L.frames;   // frames (frame pairs) a column of the grid walks
+    long long td = (dirs * wg_frames + target_wgs - 1) / target_wgs;
+    if (dirs * wg_frames < (long long)n_cus * group) {
+        td = (dirs * wg_frames + n_cus - 1) / n_cus;
         td = round_up((int)(td < 1 ? 1 : td), p.dpw);
     } else {
         td = round_up((int)(td < group ? group : td > 512 ? 512 : td), group);
@@ -1774,7 +2083,8 @@ hipError_t launch_digest(const DasLaunch& L, const DasPlan& plan, int32_t* d_dig
 {
     // what the kernel looks back by beyond the whole-sample delay: lerp reads s[k - p - 1], hybrid starts its window at
     // s[k - p - 1 - T/2] (T = 8)
-    const int arrays = (L.algo == ALGO_LERP) ? 2 : 1, bias = (L.algo == ALGO_LERP) ? 1 : (L.algo == ALGO_HYBRID) ? 5 : 0;
+    // (`arrays`: rows of one staged mic in units of its shifted copies -- samples, lerp's differences, and both frames of the pair kernel)
+    const int arrays = ((L.algo == ALGO_LERP) ? 2 : 1) * (plan.nf == 2 ? 2 : 1), bias = (L.algo == ALGO_LERP) ? 1 : (L.algo == ALGO_HYBRID) ? 5 : 0;
     if (L.algo == ALGO_HYBRID || direct) {
         hipLaunchKernelGGL(digest_kernel, dim3(1024), dim3(256), 0, stream, L.tab.whole, d_digest, (long long)L.n_dirs * L.n_mics, L.n_mics, plan.mic_chunk,
                            arrays, plan.row_stride, plan.lead, bias, plan.copies);
