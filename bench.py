@@ -365,7 +365,9 @@ def main():
                        "frames_per_step_global": frames_global, "directions_per_gpu": hi - lo,
                        "parallelism": "directions sharded over %d GPU(s) + RCCL all-gather of the heat-maps" % world if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": ("copies::das_copies_kernel<%s>" if args.algo in ("pad", "lerp") and N <= 256 else "das_mimo_kernel<%s>") % args.algo, "kernel_ms": kernel_ms,
+                         "traffic": traffic, "kernel": {5: "copies::das_pair_kernel<%s>", 2: "copies::das_copies_kernel<%s>", 3: "copies::das_copies_kernel<%s, DIRECT>",
+                                                        4: "copies::das_copies_kernel<%s>"}.get(nat.lib.bf_last_das_variant(), "das_mimo_kernel<%s>") % args.algo,
+                         "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "gather-accumulate kernel: tables stay L2-resident across the frames of a launch, sample quads are re-read "
                                  "from LDS only when a direction's delay differs from its neighbour's; the binding resource is VALU issue, "

@@ -286,14 +286,13 @@ def test_batched_device_path(nat, algo):
     assert np.array_equal(torch.cat([lo, hi], dim=1).cpu().numpy(), ref_imgs)
 
 
-@pytest.mark.parametrize("n_active,F", [(64, 5), (64, 2), (32, 3)])
+@pytest.mark.parametrize("cfg,n_active,F", [("cfg2", 64, 5), ("cfg2", 64, 2), ("cfg2", 32, 3), ("shipped", 256, 3)])
 @pytest.mark.parametrize("algo", ["pad", "lerp"])
-def test_batched_frame_pairs(nat, oracle_lib, algo, n_active, F):
+def test_batched_frame_pairs(nat, oracle_lib, algo, cfg, n_active, F):
     """The two-frames-per-workgroup kernel: odd frame counts (the last workgroup row owns a single frame), a subset of the
-    microphone rows (adaptive_array): bit-identical to the CPU oracle, frame by frame, and to the one-frame kernel."""
+    microphone rows (adaptive_array), the as-shipped 256-microphone array (16 chunks): bit-identical to the CPU oracle, frame by frame, and to the one-frame kernel."""
     torch = _torch()
     import synth
-    cfg = "cfg2"
     c = util.configure(cfg)
     M, N, X, Y = c["M"], c["N"], c["X"], c["Y"]
     D = X * Y

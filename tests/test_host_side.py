@@ -67,15 +67,15 @@ def test_plan_geometry(native):
     out = (C.c_longlong * 10)()
     util.configure("cfg2")
     # lerp at N = 256, one frame: shifted-copies layout, 32 mics x (2 sample copies + 2 difference copies) per chunk, one
-    # 1024-thread workgroup per CU, 8 directions per wave; small delays get the compile-time row stride (lead 48)
+    # 1024-thread workgroup per CU, 8 directions per wave; small delays get the compile-time row stride (lead 56)
     assert native.lib.bf_plan_das(native.LERP, 64, 1, 0, 101 * 101, 12, 256, out) == 0
     nc, lead, rs, mc, nch, waves, dpw, tile, ntiles, lds = list(out)
     assert (nc, mc, nch, waves, dpw) == (4, 32, 2, 16, 8) and lds <= 160 * 1024 and ntiles % 8 == 0
-    assert (lead, rs) == (48, 304)
+    assert (lead, rs) == (56, 312)
     # a batch: two frames per workgroup, 16 mics x 2 frames per chunk
     assert native.lib.bf_plan_das(native.LERP, 64, 190, 0, 101 * 101, 12, 256, out) == 0
     nc, lead, rs, mc, nch, waves, dpw, tile, ntiles, lds = list(out)
-    assert (nc, mc, nch, waves, dpw) == (4, 16, 4, 16, 8) and lds == 16 * 2 * 4 * 304 * 4 and tile % 128 == 0 and ntiles % 8 == 0
+    assert (nc, mc, nch, waves, dpw) == (4, 16, 4, 16, 8) and lds == 16 * 2 * 4 * 312 * 4 and tile % 128 == 0 and ntiles % 8 == 0
     assert native.lib.bf_plan_das(native.PAD, 64, 190, 0, 101 * 101, 12, 256, out) == 0
     assert list(out)[3:5] == [16, 4] and out[9] == 128 * 260 * 4      # the parked power rows outgrow the pad chunk
     # a mic count that is not a multiple of 16 keeps one frame per workgroup

@@ -693,7 +693,7 @@ template <int NSEG>
 struct Geo {
     static constexpr int kDw = NSEG == 1 ? 8 : NSEG == 2 ? 8 : 4;   // directions per wave
     static constexpr int kBatch = 4 / NSEG;                          // mics whose reads are in flight together
-    static constexpr int kLead = NSEG == 1 ? 48 : 64;                // zero prefix of the fixed-stride variant
+    static constexpr int kLead = NSEG == 1 ? 56 : 64;                // zero prefix of the fixed-stride variant (56: the as-shipped array's delays, up to 47 samples, still fit; 32 lerp mics x 4 rows x 312 floats = 156 KiB)
     static constexpr int kRs = NSEG * 256 + kLead;                   // its row stride
     static constexpr int kPark = NSEG * 256 + 4;                     // floats per parked row of squares
     static constexpr int kFirTail = 8;                               // 8-tap FIR rows: the reference's zero padding after the block
