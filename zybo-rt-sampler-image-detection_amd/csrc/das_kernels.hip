@@ -2056,7 +2056,23 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
         td = (dirs * wg_frames + n_cus - 1) / n_cus;
         td = round_up((int)(td < 1 ? 1 : td), p.dpw);
     } else {
-        td = round_up((int)(td < group ? group : td > 512 ? 512 : td), group);
+        // A whole number of wave groups per tile, chosen by what the grid costs: workgroup id -> (tile, frame) keeps
+        // tile % 8 == id % 8, i.e. XCD x runs the tiles with tile % 8 == x for every frame (pair), 32 CUs each, so the launch
+        // takes  max_x ceil(tiles_x * frames / 32)  rounds of k groups.  (cfg2, 95 frame pairs, lerp: k = 2 or 5 -> 30 units,
+        // 122K frames/s; k = 4 -> 36, 106K; k = 8 -> 48, 80K: measured.)  Ties go to the first of 2, 3, .., 8, 1.
+        const int xcds = 8, cus_per_xcd = n_cus >= xcds ? n_cus / xcds : 1;
+        long long best_cost = -1;
+        int best_k = 4;
+        for (int i = 0; i < 8; ++i) {
+            const int k = i < 7 ? i + 2 : 1;
+            const long long tiles = (dirs + (long long)k * group - 1) / ((long long)k * group);
+            const long long tiles_x = tiles / xcds + (tiles % xcds ? 1 : 0);        // the busiest XCD's share
+            const long long rounds = (tiles_x * wg_frames + cus_per_xcd - 1) / cus_per_xcd;
+            const long long cost = rounds * k;
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_k = k; }
+        }
+        td = (long long)best_k * group;
+        if ((L.debug >> 8) & 15) td = (long long)((L.debug >> 8) & 15) * group;   // debug bits 8..11: tile size in groups (A/B)
     }
     p.tile_dirs = (int)td;
     p.n_tiles = round_up((int)((dirs + td - 1) / td), 8);
