@@ -43,7 +43,8 @@ struct DasLaunch {
     int image_stride, image_origin;
     int frames;
     int force_layout;        // tests/bench ($BF_LAYOUT): -1 = planner's choice, else 0 / 1 / 2 for pad and lerp at N <= 256
-    int debug;               // profiling switches ($BF_DEBUG), 0 in production: bit 0 skip the power sum (strided kernel), bit 1 run-time row stride (copies kernel)
+    int debug;               // profiling / A-B switches ($BF_DEBUG), 0 in production: bit 0 skip the power sum (strided kernel), bit 1 run-time row stride (copies kernel),
+                             // bit 2 8-wave workgroups, bit 3 16-mic chunks, bit 4 one frame per workgroup, bits 8..11 tile size in wave groups
 };
 
 // Plan chosen on the host for a launch (exposed so tests can check LDS sizing without a GPU).
