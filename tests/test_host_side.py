@@ -76,6 +76,8 @@ def test_plan_geometry(native):
     assert native.lib.bf_plan_das(native.LERP, 64, 190, 0, 101 * 101, 12, 256, out) == 0
     nc, lead, rs, mc, nch, waves, dpw, tile, ntiles, lds = list(out)
     assert (nc, mc, nch, waves, dpw) == (4, 16, 4, 16, 8) and lds == 16 * 2 * 4 * 312 * 4 and tile % 128 == 0 and ntiles % 8 == 0
+    # tile size from the per-XCD round count: 40 tiles of 2 wave groups = 5 per XCD, 5 * 95 frame pairs on 32 CUs = 15 rounds
+    assert (tile, ntiles) == (256, 40)
     assert native.lib.bf_plan_das(native.PAD, 64, 190, 0, 101 * 101, 12, 256, out) == 0
     assert list(out)[3:5] == [16, 4] and out[9] == 128 * 260 * 4      # the parked power rows outgrow the pad chunk
     # a mic count that is not a multiple of 16 keeps one frame per workgroup
