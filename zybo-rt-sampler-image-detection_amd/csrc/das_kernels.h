@@ -64,7 +64,7 @@ struct DasPlan {
     int nf;          // frames a workgroup carries (2: das_pair_kernel -- pad / lerp at N <= 256 with the fixed row stride, a multiple of 16 mics and two or more frames)
     int copies;      // layout 2: shifted copies per staged array (2: the sweep of pad / lerp, 4: FIR flavours and the DIRECT variant)
     int tile_dirs;   // directions per workgroup
-    int n_tiles;     // padded to a multiple of 8 (XCD affinity: tile % 8 == workgroup id % 8)
+    int n_tiles;     // padded to a multiple of 8 (XCD affinity: tile % 8 == workgroup id % 8) unless the launch's table fits every XCD's L2
     size_t lds_bytes;
 };
 

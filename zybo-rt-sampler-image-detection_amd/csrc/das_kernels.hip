@@ -2049,6 +2049,7 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
     // host-pointer API), where latency matters: then every CU gets a tile, even if that leaves waves of a group idle.
     const int group = p.waves * p.dpw;
     const long long dirs = (long long)(L.dir_end - L.dir_begin);
+    bool spread = false;   // no XCD affinity of the tiles (see below)
     const long long target_wgs = (long long)n_cus * 4;
     const long long wg_frames = p.nf == 2 ? (L.frames + 1) / 2 : L.frames;   // frames (frame pairs) a column of the grid walks
     long long td = (dirs * wg_frames + target_wgs - 1) / target_wgs;
@@ -2056,10 +2057,18 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
         td = (dirs * wg_frames + n_cus - 1) / n_cus;
         td = round_up((int)(td < 1 ? 1 : td), p.dpw);
     } else {
-        // A whole number of wave groups per tile, chosen by what the grid costs: workgroup id -> (tile, frame) keeps
-        // tile % 8 == id % 8, i.e. XCD x runs the tiles with tile % 8 == x for every frame (pair), 32 CUs each, so the launch
-        // takes  max_x ceil(tiles_x * frames / 32)  rounds of k groups.  (cfg2, 95 frame pairs, lerp: k = 2 or 5 -> 30 units,
-        // 122K frames/s; k = 4 -> 36, 106K; k = 8 -> 48, 80K: measured.)  Ties go to the first of 2, 3, .., 8, 1.
+        // A whole number of wave groups per tile, chosen by what the grid costs.  Workgroup ids go round-robin over the 8 XCDs.
+        //   * Large tables: workgroup id -> (tile, frame) with the tile count padded to a multiple of 8 keeps
+        //     tile % 8 == id % 8, so every XCD's L2 serves only its own tiles' table rows for all frames; XCD x then runs
+        //     the tiles with tile % 8 == x on its 32 CUs and the launch takes  max_x ceil(tiles_x * frames / 32)  rounds of
+        //     k groups.  (cfg2, 95 frame pairs, lerp: k = 2 or 5 -> 30 units, 122K frames/s; k = 4 -> 36, 106K; k = 8 -> 48,
+        //     80K: measured.)
+        //   * Tables that fit every XCD's L2 whole (a rank's direction shard of bench.py --gpus 4 / 8): no padding, every
+        //     tile's workgroups spread over the XCDs, ceil(tiles * frames / CUs) rounds -- pinning 10 tiles to 8 XCDs left
+        //     a rank of the 8-GPU shape at 63 % of the one-GPU rate.
+        // Ties go to the first of 2, 3, .., 8, 1.
+        const size_t table_bytes = (size_t)dirs * (size_t)L.n_mics * 4u * ((L.algo == ALGO_LERP ? 2u : 1u) + (fir ? (size_t)L.n_taps : 0u));
+        spread = table_bytes <= ((size_t)3 << 20) && !(L.debug & 32);                  // debug bit 5: A/B switch
         const int xcds = 8, cus_per_xcd = n_cus >= xcds ? n_cus / xcds : 1;
         long long best_cost = -1;
         int best_k = 4;
@@ -2067,7 +2076,7 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
             const int k = i < 7 ? i + 2 : 1;
             const long long tiles = (dirs + (long long)k * group - 1) / ((long long)k * group);
             const long long tiles_x = tiles / xcds + (tiles % xcds ? 1 : 0);        // the busiest XCD's share
-            const long long rounds = (tiles_x * wg_frames + cus_per_xcd - 1) / cus_per_xcd;
+            const long long rounds = spread ? (tiles * wg_frames + n_cus - 1) / n_cus : (tiles_x * wg_frames + cus_per_xcd - 1) / cus_per_xcd;
             const long long cost = rounds * k;
             if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_k = k; }
         }
@@ -2075,7 +2084,7 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
         if ((L.debug >> 8) & 15) td = (long long)((L.debug >> 8) & 15) * group;   // debug bits 8..11: tile size in groups (A/B)
     }
     p.tile_dirs = (int)td;
-    p.n_tiles = round_up((int)((dirs + td - 1) / td), 8);
+    p.n_tiles = spread ? (int)((dirs + td - 1) / td) : round_up((int)((dirs + td - 1) / td), 8);
     *plan = p;
     if (why) *why = kWhy[0];
     return 0;
