@@ -2068,7 +2068,7 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
         //     a rank of the 8-GPU shape at 63 % of the one-GPU rate.
         // Ties go to the first of 2, 3, .., 8, 1.
         const size_t table_bytes = (size_t)dirs * (size_t)L.n_mics * 4u * ((L.algo == ALGO_LERP ? 2u : 1u) + (fir ? (size_t)L.n_taps : 0u));
-        spread = table_bytes <= ((size_t)3 << 20) && !(L.debug & 32);                  // debug bit 5: A/B switch
+        spread = (table_bytes <= ((size_t)3 << 20) && !(L.debug & 32)) || (L.debug & 64);   // debug bits 5 / 6: A/B switches (never / always)
         const int xcds = 8, cus_per_xcd = n_cus >= xcds ? n_cus / xcds : 1;
         long long best_cost = -1;
         int best_k = 4;
