@@ -315,6 +315,38 @@ def test_batched_frame_pairs(nat, oracle_lib, algo, cfg, n_active, F):
         assert np.array_equal(got[f], orc.mimo_range(ALGOS[algo], frames[f], mics, 0, D).reshape(-1)), f
 
 
+@pytest.mark.parametrize("algo", ["pad", "lerp"])
+def test_batched_frame_pairs_short_block(nat, oracle_lib, algo):
+    """The pair kernel on a block that does not fill its 256-sample rows (N = 200) and a grid that is not a multiple of the
+    128 directions a workgroup pass carries: bit-identical to the CPU oracle."""
+    torch = _torch()
+    from interface import config
+    from lib import directions
+    M, N, X, Y, T, F = 64, 200, 37, 31, 8, 3
+    config.configure(N_MICROPHONES=M, ACTIVE_TILES=1, N_SAMPLES=N, MAX_RES_X=X, MAX_RES_Y=Y, N_TAPS=T)
+    try:
+        delays = directions.calculate_delays()
+        table = delays.astype(int).astype(np.int32) if algo == "pad" else np.float32(delays)
+        rng = np.random.default_rng(11)
+        frames = (rng.standard_normal((F, M, N)) * 0.25).astype(np.float32)
+        mics = np.arange(M, dtype=np.int32)
+        orc = oracle_lib.Oracle(N, X, Y, T)
+        orc.load(ALGOS[algo], table)
+        run_product(nat, algo, table, frames[0], mics)          # loads the table into the library
+        D = X * Y
+        d_sig = torch.from_numpy(frames).cuda()
+        d_img = torch.full((F, D), float("nan"), dtype=torch.float32, device="cuda")
+        assert nat.lib.bf_das_device(ALGOS[algo], d_sig.data_ptr(), M, d_img.data_ptr(), D, F, nat.iptr(mics), M, 0, D,
+                                     torch.cuda.current_stream().cuda_stream) == 0, nat.check()
+        torch.cuda.synchronize()
+        assert nat.lib.bf_last_das_variant() == 5
+        got = d_img.cpu().numpy()
+        for f in range(F):
+            assert np.array_equal(got[f], orc.mimo_range(ALGOS[algo], frames[f], mics, 0, D).reshape(-1)), f
+    finally:
+        util.configure("cfg1")
+
+
 def test_full_size_properties(nat):
     """BASELINE cfg2 at bench size (190 frames): size-independent properties of the power map.
        * scaling a block by 2 scales its map by exactly 4 (power-of-two scaling is exact in float32);
