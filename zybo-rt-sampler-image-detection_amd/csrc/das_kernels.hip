@@ -13,12 +13,16 @@
 // Two families of kernels (DESIGN.md section 4.1 has the measurements behind each choice):
 //   * das_mimo_kernel / das_miso_kernel ("strided": lane l owns samples l, l+64, ...): any N <= 1024, any tap count,
 //     single beams; table entries by vector load + v_readlane.  The first implementation; now the general fallback.
-//   * copies::das_copies_kernel ("shifted copies": four copies of every staged row shifted by 0..3 samples, lane l owns
-//     the aligned quad 4l..4l+3): pad / lerp for 128 < N <= 1024 and the 8-tap FIR flavours for N <= 256 -- the kernels
-//     every BASELINE configuration runs.  pad / lerp sweep a mic over the wave's 8 directions and re-read its quad from
-//     LDS only when the delay changes from one direction to the next.
-// Workgroup id -> (tile, frame) keeps tile % 8 == id % 8, i.e. all frames' workgroups of one direction tile
-// land on one XCD and re-read that tile's table slice from the XCD's own L2.
+//   * copies::das_copies_kernel ("shifted copies": every staged row kept in copies shifted by one sample each, lane l owns
+//     the quad 4l..4l+3): pad / lerp for 128 < N <= 1024 and the 8-tap FIR flavours for N <= 256.  pad / lerp sweep a mic
+//     over the wave's 8 directions and re-read its quad from LDS only when the delay changes from one direction to the
+//     next (two copies, 8-byte reads); the FIR flavours and the direction-outer variant for tables without structure read
+//     at every step (four copies, 16-byte reads).
+//   * copies::das_pair_kernel: the same sweep with TWO frames per workgroup -- batched pad / lerp launches at N <= 256,
+//     what the bench and every multi-frame caller run: the per-step scalar work is shared by both frames.
+// Workgroup id -> (tile, frame): with large tables the tile count is padded to a multiple of 8 so that tile % 8 == id % 8,
+// i.e. all frames' workgroups of one direction tile land on one XCD and re-read that tile's table slice from the XCD's
+// own L2; tables that fit every L2 spread their tiles over all XCDs (plan_das sizes the tiles by the rounds either costs).
 //
 // Roofline: gather-accumulate, no MFMA, not HBM-bound (tables and samples are reused out of L2 / LDS); the binding
 // resource is VALU issue.  See DESIGN.md section 5 for the byte / instruction accounting.
@@ -613,19 +617,21 @@ __global__ void __launch_bounds__(64) das_miso_kernel(BF_TABLE_PARAMS, const flo
 // ==================================================================================================
 // "Shifted-copies" layout (copies::das_copies_kernel below).
 //
-//   * every staged mic row is kept in FOUR copies shifted by 0..3 samples, so a delay p = 4q + r becomes a
-//     16-byte-ALIGNED read from copy r at quad offset -q: no sub-quad alignment work, no branches;
+//   * every staged mic row is kept in C copies shifted by 0..C-1 samples, so a delay p = C q + r becomes an ALIGNED read
+//     from copy r (C = 4: 16-byte ds_read_b128 for the kernels that read at every step; C = 2: pairs of 8-byte
+//     ds_read_b64 for the pad / lerp sweep, which re-reads rarely -- half the staging and half the LDS per mic): no
+//     sub-quad alignment work, no branches;
 //   * lane l owns the four consecutive samples 4l..4l+3 of a 256-sample segment (one quad read = a whole segment row);
 //   * for lerp the staged rows also carry D[i] = s[i+1] - s[i] (rounded exactly as the reference's subtraction,
 //     D[-1] = 0), so a sample is fma(h, D[i], s[i]) -- the reference's own two roundings -- and the i < 0 guard
 //     falls out of the zero prefix;
-//   * the copies of a whole frame do not fit in LDS, so the mics are staged in chunks of up to 16 and every wave
+//   * the copies of a whole frame do not fit in LDS, so the mics are staged in chunks of up to 32 and every wave
 //     carries its directions' accumulators across the chunks; the next chunk's samples are already in registers
 //     (global loads issued a chunk ahead) when the buffer is rewritten;
 //   * the chunk buffer doubles as the scratch for the k-ordered power sum.
 // Mic order and operation order are unchanged, so the maps stay bit-identical to the CPU reference.
 // Digest of a `whole` table for the shifted-copies layout: entry (d, m) -> LDS byte offset of the aligned quad row that
-// direction d reads for staged mic m % mic_chunk (copy (p & 3), shifted back by p >> 2 quads; lerp reads one sample
+// direction d reads for staged mic m % mic_chunk (copy p mod C, shifted back by p - p mod C samples; lerp reads one sample
 // earlier, p + 1).  Built once per (table, layout) so that the hot loop gets its addresses with scalar loads only.
 __global__ void __launch_bounds__(256) digest_kernel(const int32_t* __restrict__ whole, int32_t* __restrict__ digest, long long entries, int n_mics,
                                                      int mic_chunk, int arrays, int row_stride, int lead, int bias, int ncopies)
