@@ -1369,7 +1369,6 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
                     if constexpr (DOFF > 0) issue_quads_i<DOFF>(sq, dq, e, lb);
                     else issue_quads<NSEG, kLerp>(sq, dq, e, lb, d_off);
                 };
-                if constexpr (kPipe) issue(S[0], Dq[0], E[0].e[0]);
                 auto mic = [&](int m, auto pc, auto kc) {
                     constexpr int P = kPipe ? decltype(pc)::value : 0, K = decltype(kc)::value, K1 = (K + 1) % 3, K2 = (K + 2) % 3;
                     const Entries& cur = E[K];
@@ -1410,8 +1409,12 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
                 using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
                 // The planner's usual chunk sizes get the mic count at compile time: whole six-mic trips without the per-mic
                 // "is there another mic" tests, table addresses as immediates off one pointer per trip.
+                // (The first request of quads and the final wait live INSIDE each alternative: no read may be in flight across
+                // the C++ branch that picks one -- the compiler copies live registers at such branches and merges, and a copy
+                // of a register whose read has not landed yet carries the old value.)
                 auto trips = [&](auto mcc_c) {
                     constexpr int MCC = decltype(mcc_c)::value;
+                    if constexpr (kPipe) issue(S[0], Dq[0], E[0].e[0]);
                     if constexpr (MCC > 0) {
                         constexpr int R0 = MCC / 6 * 6;
 #pragma unroll 1
@@ -1436,6 +1439,9 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
                             et += 6 * DW; ht += 6 * DW;
                         }
                     }
+                    // nothing may stay in flight into registers the compiler is about to move or reuse
+                    await_quads<NSEG>(S[0], Dq[0]);
+                    if constexpr (kPipe) await_quads<NSEG>(S[NQ - 1], Dq[NQ - 1]);
                 };
                 if constexpr (NSEG == 1) {
                     if (mcc == 32) trips(std::integral_constant<int, 32>{});
@@ -1444,9 +1450,6 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
                 } else {
                     trips(I0{});
                 }
-                // nothing may stay in flight into registers the compiler is about to reuse
-                await_quads<NSEG>(S[0], Dq[0]);
-                if constexpr (kPipe) await_quads<NSEG>(S[NQ - 1], Dq[NQ - 1]);
             };
             if constexpr (FIR) {
                 if (mcc == 16) fir_directions(std::integral_constant<int, 16>{});
