@@ -5,7 +5,8 @@ their own; the compiler does not know those registers have a read in flight.  Th
 a register between the request and the wait (a v_mov would carry the old value, and the late-landing data would hit a
 register the compiler already considers free).  It does insert such copies at C++-level branches and merges, so no read may
 be in flight across one.  This script scans the gfx950 assembly of every das_copies_kernel / das_pair_kernel instantiation
-for a v_mov that reads a register between a ds_read into it and the next `s_waitcnt lgkmcnt(0)`.
+for a vector instruction that reads or writes a register while a ds_read into it is outstanding (lgkmcnt accounting:
+LDS reads and writes and scalar loads in issue order, `s_waitcnt lgkmcnt(k)` retires all but the k youngest).
 
 usage: python scripts/dev/check_inflight_copies.py [file.s]     (without a file: compiles das_kernels.hip to assembly first)"""
 import os, re, subprocess, sys, tempfile
@@ -22,11 +23,18 @@ def compile_asm(out):
 
 def scan(path):
     """-> (kernels seen, [(kernel, line number, instruction), ...])"""
-    name, pending, bad, kernels = None, {}, [], 0
+    name, queue, bad, kernels = None, [], [], 0     # queue: registers of the outstanding LGKM operations, oldest first
+
+    def pending():
+        regs = set()
+        for q in queue:
+            regs |= q
+        return regs
+
     for i, line in enumerate(open(path)):
         m = re.match(r"^(_ZN2bf\S*(das_copies_kernel|das_pair_kernel)\S*):", line)
         if m:
-            name, pending, kernels = m.group(1), {}, kernels + 1
+            name, queue, kernels = m.group(1), [], kernels + 1
             continue
         if name is None:
             continue
@@ -34,19 +42,41 @@ def scan(path):
         if "s_endpgm" in l:
             name = None
             continue
-        m = re.match(r"ds_read_b(64|128) v\[(\d+):(\d+)\]", l)
+        m = re.match(r"ds_read\w* (v\[(\d+):(\d+)\]|v(\d+))", l)
         if m:
-            for r in range(int(m.group(2)), int(m.group(3)) + 1):
-                pending[r] = i
+            lo, hi = (int(m.group(2)), int(m.group(3))) if m.group(2) else (int(m.group(4)), int(m.group(4)))
+            queue.append(set(range(lo, hi + 1)))
             continue
-        if l.startswith("s_waitcnt") and "lgkmcnt(0)" in l:
-            pending = {}
+        if re.match(r"(ds_\w+|s_load_\w+|s_buffer_load_\w+) ", l):
+            queue.append(set())                      # LDS writes and scalar loads count in lgkmcnt too
             continue
-        m = re.match(r"v_mov_b(32|64)_e32 (v\[?\d+(?::\d+)?\]?), (v\[?\d+(?::\d+)?\]?)", l)
-        if m and pending:
-            nums = [int(x) for x in re.findall(r"\d+", m.group(3))]
-            if any(r in pending for r in range(nums[0], nums[-1] + 1)):
-                bad.append((name, i + 1, l))
+        if l.startswith("s_waitcnt"):
+            m = re.search(r"lgkmcnt\((\d+)\)", l)
+            if m:                                    # (LDS returns in order: all but the k youngest operations are done)
+                k = int(m.group(1))
+                queue = queue[len(queue) - k:] if k else []
+            continue
+        inflight = pending()
+        if not inflight:
+            continue
+        if re.match(r"(v_|ds_write|global_store|scratch_store|buffer_store)", l):
+            # any vector instruction READING such a register (a v_mov copy at a branch or merge is the case that was found)
+            ops = l.split(None, 1)[1] if " " in l else ""
+            first_is_dest = l.startswith("v_") and not re.match(r"v_(cmp|cmpx)", l)
+            toks = re.findall(r"v\[(\d+):(\d+)\]|\bv(\d+)\b", ops)
+            for n, t in enumerate(toks):
+                if n == 0 and first_is_dest:
+                    continue
+                lo, hi = (int(t[0]), int(t[1])) if t[0] else (int(t[2]), int(t[2]))
+                if any(r in inflight for r in range(lo, hi + 1)):
+                    bad.append((name, i + 1, "READ  " + l))
+                    break
+        # ... and nothing else may WRITE such a register before the wait (the compiler reusing it for another value)
+        m = re.match(r"(v_(?!cmp|readlane|readfirstlane)\w+|global_load_\w+|scratch_load_\w+|buffer_load_\w+) (v\[(\d+):(\d+)\]|v(\d+))[, ]", l)
+        if m:
+            lo, hi = (int(m.group(3)), int(m.group(4))) if m.group(3) else (int(m.group(5)), int(m.group(5)))
+            if any(r in inflight for r in range(lo, hi + 1)):
+                bad.append((name, i + 1, "WRITE " + l))
     return kernels, bad
 
 
