@@ -347,6 +347,29 @@ def test_batched_frame_pairs_short_block(nat, oracle_lib, algo):
         util.configure("cfg1")
 
 
+@pytest.mark.parametrize("cfg,algo,F", [("cfg2", "hybrid", 3), ("cfg5", "lerp", 2), ("cfg5", "pad", 3)])
+def test_batched_large_tables_frame_inner_mapping(nat, cfg, algo, F):
+    """Tables beyond the L2s (cfg2's 21 MB of hybrid taps, cfg5's 268 MB digest): the launch maps workgroup ids so that an
+    XCD runs all frames of a direction tile back to back.  Every frame of the batch must equal the one-frame call."""
+    torch = _torch()
+    import synth
+    c = util.configure(cfg)
+    try:
+        M, N, D = c["M"], c["N"], c["X"] * c["Y"]
+        frames = synth.frame_batch(M, N, F)
+        mics = np.arange(M, dtype=np.int32)
+        table = util.table_for(algo, cfg)
+        ref = np.stack([run_product(nat, algo, table, frames[f], mics) for f in range(F)])
+        d_sig = torch.from_numpy(frames).cuda()
+        d_img = torch.full((F, D), float("nan"), dtype=torch.float32, device="cuda")
+        assert nat.lib.bf_das_device(ALGOS[algo], d_sig.data_ptr(), M, d_img.data_ptr(), D, F, nat.iptr(mics), M, 0, D,
+                                     torch.cuda.current_stream().cuda_stream) == 0, nat.check()
+        torch.cuda.synchronize()
+        assert np.array_equal(d_img.cpu().numpy(), ref.reshape(F, D))
+    finally:
+        util.configure("cfg1")
+
+
 def test_full_size_properties(nat):
     """BASELINE cfg2 at bench size (190 frames): size-independent properties of the power map.
        * scaling a block by 2 scales its map by exactly 4 (power-of-two scaling is exact in float32);

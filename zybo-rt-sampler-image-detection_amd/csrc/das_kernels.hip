@@ -48,8 +48,29 @@ struct KArgs {
     float inv_n;
     int debug;   // profiling only (BF_DEBUG): bit 0 = skip the ordered power sum (wrong images)
     int n_frames;   // frames of the launch (das_pair_kernel: whether a workgroup's second frame exists)
+    int wg_frames, frame_inner;   // workgroup id -> (tile, frame [pair]): see tile_and_frame()
     long long digest_h_off;   // shifted-copies pad / lerp: where the grouped lerp weights start in the digest buffer (floats)
 };
+
+// Workgroup id -> (direction tile, frame or frame pair).  Ids go round-robin over the 8 XCDs.
+//   frame_inner == 0:  tile = id % n_tiles, frame = id / n_tiles.  With n_tiles a multiple of 8 a tile's workgroups stay on
+//                      one XCD (tile % 8 == id % 8); an XCD walks its tiles frame by frame, so a tile's table slice is
+//                      re-used out of L2 only if the XCD's share of the whole table stays resident (cfg2: 650 KB).
+//   frame_inner == 1:  tables beyond that (cfg5: 33 MB per XCD): XCD x = id % 8 walks tile x, x + 8, .. and runs ALL frames of
+//                      a tile back to back (its 32 CUs hold 32 frames of the same tile at a time), so the slice comes from
+//                      HBM once instead of once per frame.
+__device__ __forceinline__ void tile_and_frame(const KArgs& a, int* tile, int* frame)
+{
+    const unsigned id = blockIdx.x;
+    if (a.frame_inner) {
+        const unsigned x = id & 7u, j = id >> 3;
+        *tile = (int)(x + 8u * (j / (unsigned)a.wg_frames));
+        *frame = (int)(j % (unsigned)a.wg_frames);
+    } else {
+        *tile = (int)(id % (unsigned)a.n_tiles);
+        *frame = (int)(id / (unsigned)a.n_tiles);
+    }
+}
 
 // The read-only tables are separate `const __restrict__` kernel parameters on purpose: only then can the
 // compiler prove that no store in the kernel clobbers them and fetch the wave-uniform table entries with
@@ -1022,8 +1043,8 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int tile = (int)(blockIdx.x % (unsigned)a.n_tiles);
-    const int frame = (int)(blockIdx.x / (unsigned)a.n_tiles);
+    int tile, frame;
+    tile_and_frame(a, &tile, &frame);
     const int tile_begin = a.dir_begin + tile * a.tile_dirs;
     if (tile_begin >= a.dir_end) return;
     const int tile_end = min(tile_begin + a.tile_dirs, a.dir_end);
@@ -1631,8 +1652,9 @@ __global__ void __launch_bounds__(1024, 4) das_pair_kernel(BF_TABLE_PARAMS, KArg
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int tile = (int)(blockIdx.x % (unsigned)a.n_tiles);
-    const int f0 = 2 * (int)(blockIdx.x / (unsigned)a.n_tiles);
+    int tile, fpair;
+    tile_and_frame(a, &tile, &fpair);
+    const int f0 = 2 * fpair;
     const bool two = f0 + 1 < a.n_frames;                      // an odd frame count: the last workgroup row computes its frame twice
     const int f1 = two ? f0 + 1 : f0;
     const int tile_begin = a.dir_begin + tile * a.tile_dirs;
@@ -1948,6 +1970,8 @@ KArgs make_args(const DasLaunch& L, const DasPlan& plan)
     a.inv_n = 1.0f / (float)L.n_mics;
     a.debug = L.debug;
     a.n_frames = L.frames;
+    a.wg_frames = plan.nf == 2 ? (L.frames + 1) / 2 : L.frames;
+    a.frame_inner = plan.frame_inner;
     a.digest_h_off = (plan.layout == 2 && L.algo == ALGO_LERP) ? grouped_entries_for_args(L, plan) : 0;
     return a;
 }
@@ -1968,6 +1992,7 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
 
     DasPlan p{};
     p.nf = 1;
+    p.frame_inner = 0;
     int nc = (L.n_samples + kWave - 1) / kWave;
     p.nc = nc <= 1 ? 1 : nc <= 2 ? 2 : nc <= 4 ? 4 : nc <= 8 ? 8 : 16;
     const int T = fir ? L.n_taps : 0;
@@ -2078,6 +2103,8 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
         // Ties go to the first of 2, 3, .., 8, 1.
         const size_t table_bytes = (size_t)dirs * (size_t)L.n_mics * 4u * ((L.algo == ALGO_LERP ? 2u : 1u) + (fir ? (size_t)L.n_taps : 0u));
         spread = (table_bytes <= ((size_t)3 << 20) && !(L.debug & 32)) || (L.debug & 64);   // debug bits 5 / 6: A/B switches (never / always)
+        // an XCD's share of the table beyond its L2: all frames of a tile back to back (tile_and_frame); debug bit 7: never
+        p.frame_inner = (!spread && p.layout == 2 && table_bytes > ((size_t)16 << 20) && wg_frames > 1 && !(L.debug & 128)) ? 1 : 0;
         const int xcds = 8, cus_per_xcd = n_cus >= xcds ? n_cus / xcds : 1;
         long long best_cost = -1;
         int best_k = 4;
