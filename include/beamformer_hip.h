@@ -25,6 +25,8 @@
 #ifndef BEAMFORMER_HIP_H
 #define BEAMFORMER_HIP_H
 
+#include <stdbool.h>   /* load(bool), as PC/src/api.h:4 */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -78,6 +80,27 @@ void mimo_truncated(float *image, int *adaptive_array, int n);                  
 void load_coefficients2(int *whole_samples, int n);                                       /* api.h:17 */
 void miso_steer_listen(float *out, int *adaptive_array, int n, int steer_offset);         /* api.h:19 */
 
+/* ---- PC/src/api.h:6-9,41-45: the process management around the path.  Exported so that the reference's main.pyx
+ * (cdef extern block, PC/src/main.pyx:33-60) links against this library unchanged.  What they manage in the reference
+ * -- the forked UDP receiver with its SysV ring buffer (api.c:874-939) and the forked PortAudio playback child
+ * (api.c:491-543, 583-640) -- is live-hardware I/O outside the beamforming path:
+ *   load            no receiver is forked: records an error and returns -1 (frames arrive through bf_publish_frame);
+ *   stop_receiving  drops the published frame (get_data then reports "no frame published");
+ *   signal_handler  no-op;
+ *   load_miso       initialises the listen state exactly as miso_init_shared_memory does (api.c:461-489: n = 1,
+ *                   adaptive_array all zero, steer_offset 0) and returns 0; no playback child is started --
+ *                   bf_miso_listen_block below is the body of its loop;
+ *   load_pa         the microphone set of the listening beam (api.c:553-567);
+ *   steer           the flat table offset of the listening beam (api.c:576-581);
+ *   stop_miso       clears the listen state. ---- */
+int load(bool replay_mode);                                                               /* api.h:6  */
+void stop_receiving(void);                                                                /* api.h:8  */
+void signal_handler(void);                                                                /* api.h:9  */
+int load_miso(void);                                                                      /* api.h:42 */
+void load_pa(int *adaptive_array, int n);                                                 /* api.h:43 */
+void stop_miso(void);                                                                     /* api.h:44 */
+void steer(int offset);                                                                   /* api.h:45 */
+
 /* ===================================================================== PART 2: extensions */
 
 enum bf_algo {
@@ -113,6 +136,12 @@ int bf_set_device(int device);
 
 /* Frame hand-off for the api.h shims: copies n_microphones*n_samples floats (mic-major). */
 void bf_publish_frame(const float *signals);
+/* One trip of the reference's playback loop (miso_loop, PC/src/api.c:505-531): get_data(), miso_pad at the offset set by
+ * steer() over the microphones set by load_pa(), then out[i] = out[i] / n * mic_gain (MIC_GAIN, config.json:62).
+ * out = float32 [N_SAMPLES], host pointer.  Returns 0 or -1. */
+int bf_miso_listen_block(float *out, float mic_gain);
+/* The listen state as steer() / load_pa() left it: returns the steer offset, *n_out = microphone count. */
+int bf_get_steer(int *n_out);
 
 /* ---- device-resident, batched delay-and-sum (the throughput path) ----
  * d_signals : HIP device pointer, float32 [frames][m_total][N_SAMPLES], mic-major

@@ -46,6 +46,35 @@ GOLD_CASES = [(n, a, s) for n in ("cfg1", "cfg2", "shipped") for a in ("pad", "l
               if not (a == "convolve" and s == "s3")]
 GOLD_CASES += [("cfg5", "lerp", "s1"), ("cfg5", "lerp", "s2"), ("cfg5", "hybrid", "s2")]
 
+# Images taken from the reference's own C compiled where it lies (oracle/gen_golden_refc.py -> tests/golden/refc.npz): the sizes /
+# flavours its Cython wrappers cannot reach (pad at cfg5: hours of Python tap loops; mimo_convolve_naive: no wrapper calls it).
+REFC_CASES = [("cfg5", "pad", "s1"), ("cfg5", "pad", "s2")] + [(n, "naive", s) for n in ("cfg1", "cfg2") for s in ("s1", "s2")]
+
+
+@pytest.mark.parametrize("name,algo,sig", REFC_CASES)
+def test_matches_compiled_reference_c(nat, name, algo, sig):
+    """mimo_pad at 256 mics x 1024 x 361x361 and mimo_convolve_naive, through the C-ABI with host pointers, against
+    PC/src/algorithms/{pad_and_sum.c:100-143, convolve_and_sum.c:231-272} compiled by oracle/build_ref.py."""
+    c = util.configure(name)
+    g = golden("refc")
+    x = util.inputs(name)[sig]
+    assert util.sha(x) == str(g["%s/in_sha256_%s" % (name, sig)])
+    mics = np.arange(c["M"], dtype=np.int32)
+    if algo == "pad":
+        table = util.table_for("pad", name)
+        assert util.sha(table) == str(g[name + "/whole_sha256"])
+        got = run_product(nat, "pad", table, x, mics)
+    else:
+        taps = np.ascontiguousarray(util.table_for("fir_naive", name), dtype=np.float32)
+        assert util.sha(taps) == str(g[name + "/taps_sha256"])
+        got = run_product(nat, "fir_naive", taps, x, mics)
+    want = g["%s/img_%s_%s" % (name, algo, sig)]
+    got = got.reshape(want.shape)
+    assert np.isfinite(got).all()
+    assert max_rel(got, want) <= REL_TOL
+    if algo == "pad" or name == "cfg1":
+        assert got.tobytes() == want.tobytes()          # same operation order end to end: bit-identical
+
 
 @pytest.mark.parametrize("name,algo,sig", GOLD_CASES)
 def test_wrappers_match_golden(nat, name, algo, sig):
@@ -449,6 +478,17 @@ def test_beamformer_module_surface(nat, oracle_lib):
     nat.lib.load_coefficients_pad(nat.iptr(whole.ravel()), whole.size); nat.check()
     out = B.listen()
     assert out.tobytes() == orc.miso_pad(seen, whole, np.arange(M, dtype=np.int32), off).tobytes()
+    # the playback loop's body (api.c:505-531) on the state that steer() / load_pa() keep: miso_pad, then / n * MIC_GAIN
+    sub = np.array([3, 43, 44, 45, 46, 65, 66, 67], dtype=np.int32)       # microphones the dead-row mask leaves alive
+    assert nat.lib.load_miso() == 0
+    nat.lib.load_pa(nat.iptr(sub), sub.size)
+    B.steer(off)
+    blk = np.zeros(N, dtype=np.float32)
+    assert nat.lib.bf_miso_listen_block(nat.fptr(blk), C.c_float(128.0)) == 0; nat.check()
+    raw = orc.miso_pad(seen, whole, sub, off)
+    want_blk = raw / np.float32(sub.size) * np.float32(128.0)
+    assert blk.tobytes() == want_blk.astype(np.float32).tobytes() and np.abs(blk).max() > 0
+    nat.lib.stop_miso()
     B.disconnect()
 
 

@@ -62,6 +62,30 @@ def test_every_declared_symbol_is_exported(native):
     assert not missing, missing
 
 
+def test_api_h_management_symbols(native):
+    """PC/src/api.h:6-9,41-45: exported so that the reference's main.pyx links unchanged.  steer / load_pa / load_miso keep the
+    listen state (api.c:461-489, 553-581); the receiver child is out of scope, so load() fails loudly."""
+    lib = native.lib
+    n = C.c_int(-1)
+    assert lib.load_miso() == 0                       # miso_init_shared_memory: n = 1, adaptive_array zero, steer(0)
+    assert lib.bf_get_steer(C.byref(n)) == 0 and n.value == 1
+    lib.steer(12345)
+    mics = np.arange(7, dtype=np.int32)
+    lib.load_pa(native.iptr(mics), 7)
+    assert lib.bf_get_steer(C.byref(n)) == 12345 and n.value == 7
+    lib.stop_miso()
+    assert lib.bf_get_steer(C.byref(n)) == 0 and n.value == 0
+    lib.signal_handler()
+    lib.stop_receiving()
+    lib.bf_clear_error()
+    assert lib.load(True) == -1 and b"out of scope" in lib.bf_last_error()
+    lib.bf_clear_error()
+    # no listen state -> the playback-loop body refuses (and never silently computes on the CPU)
+    out = np.zeros(256, dtype=np.float32)
+    assert lib.bf_miso_listen_block(native.fptr(out), C.c_float(128.0)) == -1 and np.isnan(out).all()
+    lib.bf_clear_error()
+
+
 def test_plan_geometry(native):
     """LDS sizing / tiling chosen on the host for the BASELINE sizes (no GPU needed)."""
     out = (C.c_longlong * 10)()

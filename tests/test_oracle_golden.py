@@ -82,3 +82,76 @@ def test_cfg5_sampled_directions(oracle_lib):
         want = g["img_lerp_" + sig].reshape(-1)
         for d in picks:
             assert orc.mimo_range(1, ins[sig], mics, int(d), int(d) + 1)[0] == want[d]
+
+
+# ---- fixtures taken from the reference's C compiled where it lies (oracle/gen_golden_refc.py -> tests/golden/refc.npz)
+
+def test_refc_cfg5_pad_sampled_directions(oracle_lib):
+    """mimo_pad at 256 mics x 1024 x 361x361: 32 sampled directions of the compiled reference's images, bit for bit."""
+    name = "cfg5"
+    c, g = CONFIGS[name], golden("refc")
+    orc = oracle_lib.Oracle(c["N"], c["X"], c["Y"], c["T"])
+    mics = np.arange(c["M"], dtype=np.int32)
+    ins = util.inputs(name)
+    whole = util.table_for("pad", name)
+    assert sha(whole) == str(g["cfg5/whole_sha256"])
+    orc.load(0, whole)
+    picks = np.random.default_rng(11).choice(c["X"] * c["Y"], 32, replace=False)
+    for sig in ("s1", "s2"):
+        assert sha(ins[sig]) == str(g["cfg5/in_sha256_" + sig])
+        want = g["cfg5/img_pad_" + sig].reshape(-1)
+        for d in picks:
+            assert orc.mimo_range(0, ins[sig], mics, int(d), int(d) + 1)[0] == want[d]
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2"])
+def test_refc_convolve_naive(oracle_lib, name):
+    """mimo_convolve_naive (convolve_and_sum.c:231-272), which no Cython wrapper of the reference calls: the oracle's naive FIR
+    order against the compiled reference -- all of cfg1, 48 sampled directions of cfg2."""
+    c, g = CONFIGS[name], golden("refc")
+    orc = oracle_lib.Oracle(c["N"], c["X"], c["Y"], c["T"])
+    mics = np.arange(c["M"], dtype=np.int32)
+    taps = np.ascontiguousarray(util.table_for("fir_naive", name), dtype=np.float32)
+    assert sha(taps) == str(g[name + "/taps_sha256"])
+    orc.load(3, taps)
+    D = c["X"] * c["Y"]
+    picks = range(D) if name == "cfg1" else np.random.default_rng(13).choice(D, 48, replace=False)
+    for sig in ("s1", "s2"):
+        want = g["%s/img_naive_%s" % (name, sig)].reshape(-1)
+        x = util.inputs(name)[sig]
+        for d in picks:
+            assert orc.mimo_range(3, x, mics, int(d), int(d) + 1)[0] == want[d], (name, sig, int(d))
+
+
+# ---- the oracle against oracle/_ref directly (DESIGN.md section 2: "equals it bit for bit")
+
+@pytest.mark.parametrize("name", ["cfg1", "shipped"])
+def test_oracle_equals_compiled_reference(oracle_lib, name):
+    """Same random block through both CPU engines: every entry point the two share, whole images, bit for bit.
+    Skipped where oracle/_ref has not been built (it needs /root/reference: oracle/build_ref.py)."""
+    if not oracle_lib.RefLib.available(name):
+        pytest.skip("oracle/_ref/libref_%s.so not built" % name)
+    c = CONFIGS[name]
+    ref = oracle_lib.RefLib(name)
+    orc = oracle_lib.Oracle(c["N"], c["X"], c["Y"], c["T"])
+    rng = np.random.default_rng(17)
+    sig = (rng.standard_normal((c["M"], c["N"])) * 0.25).astype(np.float32)
+    mics = np.arange(c["M"], dtype=np.int32)
+    d = util.oracle_delays(name)
+    whole, d32 = util.table_for("pad", name), np.float32(d)
+    assert orc.mimo_pad(sig, whole, mics).tobytes() == ref.mimo_pad(sig, whole, mics).tobytes()
+    assert orc.mimo_lerp(sig, d32, mics).tobytes() == ref.mimo_lerp(sig, d32, mics).tobytes()
+    assert orc.mimo_hybrid(sig, d32, mics).tobytes() == ref.mimo_hybrid(sig, d32, mics).tobytes()
+    ow, oh = orc.lerp_tables(d32.ravel())
+    rw, rh = ref.lerp_tables(d32.ravel())
+    assert np.array_equal(ow, rw) and oh.tobytes() == rh.tobytes()
+    ow, ot = orc.hybrid_tables(d32.ravel())
+    rw, rt = ref.hybrid_tables(d32.ravel())
+    assert np.array_equal(ow, rw) and ot.tobytes() == rt.tobytes()
+    off = (c["X"] * c["Y"] // 3) * c["M"]
+    assert orc.miso_pad(sig, whole, mics, off).tobytes() == ref.miso_pad(sig, whole, mics, off).tobytes()
+    assert orc.miso_lerp(sig, d32, mics, off).tobytes() == ref.miso_lerp(sig, d32, mics, off).tobytes()
+    if name == "cfg1":
+        taps = np.ascontiguousarray(util.table_for("fir_vec", name), dtype=np.float32)
+        for vec in (False, True):
+            assert orc.mimo_convolve(sig, taps, mics, vectorized=vec).tobytes() == ref.mimo_convolve(sig, taps, mics, vectorized=vec).tobytes()

@@ -113,6 +113,8 @@ struct State {
     std::vector<float> published;        // bf_publish_frame / get_data
     std::vector<int> disabled_mics;      // get_data's dead-microphone rows
     bool disabled_default = true;
+    int steer_offset = 0;                // steer(): flat table offset of the listening beam (api.c:576-581)
+    std::vector<int> listen_mics;        // load_pa(): microphones of the listening beam (api.c:553-567); empty before load_miso / load_pa
     int last_variant = -1;               // bf_last_das_variant
     std::string err;
 };
@@ -821,6 +823,90 @@ void miso_steer_listen(float* out, int* adaptive_array, int n, int steer_offset)
     frame.resize((size_t)s.sz.n_microphones * s.sz.n_samples);
     if (!copy_published(frame.data(), true)) { poison(out, (size_t)s.sz.n_samples); return; }
     run_miso_host(bf::ALGO_PAD, s.tab[SLOT_PAD], loader_name(SLOT_PAD), false, frame.data(), out, adaptive_array, n, steer_offset, nullptr);
+}
+
+// ---- api.h:6-9,41-45: process management around the path.  The receiver / playback children are live-hardware I/O and
+// out of scope; what these keep is the STATE the path reads (listening offset, listening microphones).
+
+int load(bool replay_mode)
+{
+    (void)replay_mode;
+    std::lock_guard<std::mutex> lock(S().mu);
+    set_error("load: the UDP receiver process (PC/src/api.c:874-939) is out of scope of this library; hand frames over with bf_publish_frame");
+    return -1;
+}
+
+void stop_receiving(void)
+{
+    std::lock_guard<std::mutex> lock(S().mu);
+    S().published.clear();
+}
+
+void signal_handler(void) {}
+
+int load_miso(void)
+{
+    // miso_init_shared_memory (api.c:461-489) + the steer(0) that opens miso_loop (api.c:493): n = 1, adaptive_array all zero
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    s.listen_mics.assign(1, 0);
+    s.steer_offset = 0;
+    return 0;
+}
+
+void load_pa(int* adaptive_array, int n)
+{
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    if (!adaptive_array || n < 1) { set_error("load_pa: null or empty adaptive_array"); return; }
+    s.listen_mics.assign(adaptive_array, adaptive_array + n);
+}
+
+void stop_miso(void)
+{
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    s.listen_mics.clear();
+    s.steer_offset = 0;
+}
+
+void steer(int offset)
+{
+    std::lock_guard<std::mutex> lock(S().mu);
+    S().steer_offset = offset;
+}
+
+int bf_get_steer(int* n_out)
+{
+    std::lock_guard<std::mutex> lock(S().mu);
+    if (n_out) *n_out = (int)S().listen_mics.size();
+    return S().steer_offset;
+}
+
+int bf_miso_listen_block(float* out, float mic_gain)
+{
+    // miso_loop's body (api.c:505-531): get_data; miso_pad(signals, out, adaptive_array, n, steer_offset); out[i] /= n; out[i] *= MIC_GAIN
+    std::vector<float> frame;
+    State& s = S();
+    std::lock_guard<std::mutex> lock(s.mu);
+    sizes_from_env_once();
+    const size_t N = (size_t)s.sz.n_samples;
+    if (!out) { set_error("bf_miso_listen_block: null output"); return -1; }
+    if (s.listen_mics.empty()) { set_error("bf_miso_listen_block: load_miso / load_pa has not been called"); poison(out, N); return -1; }
+    frame.resize((size_t)s.sz.n_microphones * N);
+    if (!copy_published(frame.data(), true)) { poison(out, N); return -1; }
+    const std::string before = s.err;
+    s.err.clear();
+    std::vector<int> mics = s.listen_mics;     // run_miso_host uploads from a stable copy
+    run_miso_host(bf::ALGO_PAD, s.tab[SLOT_PAD], loader_name(SLOT_PAD), false, frame.data(), out, mics.data(), (int)mics.size(), s.steer_offset, nullptr);
+    if (!s.err.empty()) return -1;
+    s.err = before;
+    const float fn = (float)mics.size();
+    for (size_t i = 0; i < N; ++i) {
+        out[i] /= fn;
+        out[i] *= mic_gain;
+    }
+    return 0;
 }
 
 // ---------------------------------------------------------------- device-resident batched path

@@ -70,6 +70,12 @@ _sig("get_data", None, FP)
 for _n in ("pad_mimo", "lerp_mimo", "convolve_mimo_naive", "convolve_mimo_vectorized", "mimo_truncated"):
     _sig(_n, None, FP, IP, C.c_int)
 _sig("miso_steer_listen", None, FP, IP, C.c_int, C.c_int)
+_sig("load", C.c_int, C.c_bool)
+for _n in ("stop_receiving", "signal_handler", "stop_miso"):
+    _sig(_n, None)
+_sig("load_miso", C.c_int)
+_sig("load_pa", None, IP, C.c_int)
+_sig("steer", None, C.c_int)
 # PART 2 (extensions)
 _sig("bf_configure", C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
 _sig("bf_configure_from_json", C.c_int, C.c_char_p)
@@ -80,6 +86,8 @@ _sig("bf_gpu_available", C.c_int)
 _sig("bf_last_das_variant", C.c_int)
 _sig("bf_set_device", C.c_int, C.c_int)
 _sig("bf_publish_frame", None, FP)
+_sig("bf_miso_listen_block", C.c_int, FP, C.c_float)
+_sig("bf_get_steer", C.c_int, IP)
 _sig("bf_das_device", C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, IP, C.c_int, C.c_int, C.c_int, C.c_void_p)
 _sig("bf_plan_das", C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong))
 _sig("bf_ingest", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, FP)

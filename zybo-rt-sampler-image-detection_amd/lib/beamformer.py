@@ -74,6 +74,7 @@ def steer(offset: int) -> int:
     """api.c:576-581"""
     global _steer_offset
     _steer_offset = int(offset)
+    nat.lib.steer(_steer_offset)
     return _steer_offset
 
 
