@@ -131,6 +131,13 @@ int bf_gpu_available(void);
  * (direction-outer, chosen for tables without structure), 4 shifted copies (8-tap FIR), 5 shifted copies (sweep, two
  * frames per workgroup: batched launches of pad / lerp); -1 before the first launch. */
 int bf_last_das_variant(void);
+/* Planner A/B switches (the bits of $BF_DEBUG, das_kernels.hip plan_das) at run time, for tests and profiling; -1 returns to
+ * the environment's value. */
+void bf_set_debug(int flags);
+/* Profiling builds only (hipcc -DBF_STAMPS, scripts/dev/phase_stamps.py): per-phase wave time of the batched pad / lerp kernel,
+ * summed over all waves since the last clear: out16[0..7] = sweep, wait, staging, wait, wait, parking, wait, ordered power sum
+ * (s_memtime ticks), out16[8] = waves counted.  All zero in the production build.  Returns 0 or -1. */
+int bf_read_phase_stamps(unsigned long long *out16, int clear);
 /* Select the HIP device (default 0, or $BF_DEVICE) before the first load_* call. */
 int bf_set_device(int device);
 

@@ -116,6 +116,7 @@ struct State {
     int steer_offset = 0;                // steer(): flat table offset of the listening beam (api.c:576-581)
     std::vector<int> listen_mics;        // load_pa(): microphones of the listening beam (api.c:553-567); empty before load_miso / load_pa
     int last_variant = -1;               // bf_last_das_variant
+    int debug_override = -1;             // bf_set_debug: planner A/B switches at run time (tests); -1 = $BF_DEBUG
     std::string err;
 };
 
@@ -305,7 +306,7 @@ bool plan_or_error(bf::DasLaunch& L, bf::DasPlan* plan)
     static const int layout = [] { const char* e = getenv("BF_LAYOUT"); return e ? atoi(e) : -1; }();
     L.force_layout = layout;             // A/B switch for tests and profiling (see DasPlan::layout)
     static const int debug = [] { const char* e = getenv("BF_DEBUG"); return e ? atoi(e) : 0; }();
-    L.debug = debug;
+    L.debug = S().debug_override >= 0 ? S().debug_override : debug;
     const char* why = "";
     if (bf::plan_das(L, S().n_cus, plan, &why) != 0) { set_error("unsupported shape: %s", why); return false; }
     return true;
@@ -564,6 +565,13 @@ void bf_clear_error(void) { S().err.clear(); }
 // Which kernel family the last delay-and-sum launch used: 0 strided, 1 quad + DPP, 2 shifted copies / sweep, 3 shifted copies /
 // direction-outer (table without structure), 4 shifted copies / 8-tap FIR; -1 before the first launch.  For tests and tuning.
 int bf_last_das_variant(void) { return S().last_variant; }
+int bf_read_phase_stamps(unsigned long long* out16, int clear)
+{
+    std::lock_guard<std::mutex> lock(S().mu);
+    if (!out16 || !ensure_device()) return -1;
+    return HIP_OK(hipDeviceSynchronize()) && HIP_OK(bf::read_phase_stamps(out16, clear != 0)) ? 0 : -1;
+}
+void bf_set_debug(int flags) { std::lock_guard<std::mutex> lock(S().mu); S().debug_override = flags; }
 
 int bf_gpu_available(void)
 {

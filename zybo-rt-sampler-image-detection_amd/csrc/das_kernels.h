@@ -123,6 +123,9 @@ hipError_t launch_fd_cholesky_inverse(const float* rre, const float* rim, int n_
 hipError_t launch_fd_mvdr_power(const float* lire_t, const float* liim_t, const float* are, const float* aim, int n_mics, int n_dirs, int n_bins,
                                 float* d_power, float* d_work, size_t work_floats, hipStream_t stream);
 
+// Profiling build only (-DBF_STAMPS): phase totals of das_pair_kernel, see das_kernels.hip (zeros in a production build).
+hipError_t read_phase_stamps(unsigned long long* out16, bool clear);
+
 // detector post-processing (nms_kernels.hip): YOLOv5 head decode + confidence filter, greedy NMS over score-sorted candidates
 hipError_t launch_yolo_decode(const void* const raw[3], const int hs[3], const int ws[3], const int strides[3], const float* anchors,
                               int batch, int nc, int is_half, float conf_thres, float* d_boxes, float* d_scores, int* d_cls, hipStream_t stream);

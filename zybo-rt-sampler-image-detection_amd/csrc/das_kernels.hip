@@ -1558,11 +1558,12 @@ __global__ void __launch_bounds__(W * 64, 4) das_copies_kernel(BF_TABLE_PARAMS, 
 template <int ALGO>
 struct PairGeo {
     static constexpr bool kLerp = ALGO == ALGO_LERP;
-    static constexpr int kA = kLerp ? 2 : 1, kC = 2, kRs = Geo<1>::kRs, kLead = Geo<1>::kLead, kMc = 16;
+    static constexpr int kA = kLerp ? 2 : 1, kC = 2, kRs = Geo<1>::kRs, kLead = Geo<1>::kLead;
     static constexpr int kSlot = kA * kC * kRs;          // floats per staged (mic, frame)
     static constexpr int kFoff = kSlot * 4;              // bytes from a frame-0 quad to the same quad of frame 1
     static constexpr int kDoff = kC * kRs * 4;           // bytes from a sample quad to its difference quad
-    static constexpr size_t kLds = (size_t)kMc * 2 * kSlot * 4 > (size_t)128 * Geo<1>::kPark * 4 ? (size_t)kMc * 2 * kSlot * 4 : (size_t)128 * Geo<1>::kPark * 4;
+    static constexpr int kMc = 16;                       // mics per LDS image (the digest's slot count) ...
+    static constexpr int kHalf = 8;                      // ... swept and re-staged in halves of 8
 };
 
 #define BF_P_ACC(n, j, f) [a##n##0] "+v"(acc[j][f][0]), [a##n##1] "+v"(acc[j][f][1])
@@ -1643,12 +1644,27 @@ __device__ __forceinline__ void pair_steps(f32x2 (&acc)[8][2][2], Quad& S0, Quad
     }
 }
 
+// Profiling build only (-DBF_STAMPS, scripts/dev/phase_stamps.py): every wave sums the time it spends in each phase of
+// das_pair_kernel (s_memtime at the phase boundaries, which are barrier neighbours anyway) and adds the totals to
+// g_stamps[phase] when its workgroup ends.  BF_STAMP(k) closes the phase that was running and charges it to slot k:
+//   0 sweep  1 wait (chunk free)  2 staging  3 wait (chunk staged)  4 wait (power: rows free)  5 parking  6 wait (rows parked)  7 ordered sum
+#ifdef BF_STAMPS
+__device__ unsigned long long g_stamps[16];              // (sums over all waves; the flush is one atomic per wave and slot)
+#define BF_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+#define BF_STAMP(k) do { const unsigned long long st_now = __builtin_amdgcn_s_memtime(); st_acc[k] += st_now - st_prev; st_prev = st_now; } while (0)
+#define BF_STAMP_FLUSH do { if (lane == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[i], st_acc[i]); atomicAdd(&g_stamps[8], 1ull); } } while (0)
+#else
+#define BF_STAMP_DECL
+#define BF_STAMP(k)
+#define BF_STAMP_FLUSH
+#endif
+
 template <int ALGO>
 __global__ void __launch_bounds__(1024, 4) das_pair_kernel(BF_TABLE_PARAMS, KArgs a)
 {
     using G = PairGeo<ALGO>;
     constexpr bool kLerp = G::kLerp;
-    constexpr int A = G::kA, C = G::kC, RS = G::kRs, LEAD = G::kLead, MC = G::kMc, W = 16, DW = 8, kGroup = DW * W, kPark = Geo<1>::kPark;
+    constexpr int A = G::kA, C = G::kC, RS = G::kRs, LEAD = G::kLead, HC = G::kHalf, W = 16, DW = 8, kGroup = DW * W, kPark = Geo<1>::kPark;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1661,55 +1677,49 @@ __global__ void __launch_bounds__(1024, 4) das_pair_kernel(BF_TABLE_PARAMS, KArg
     if (tile_begin >= a.dir_end) return;
     const int tile_end = min(tile_begin + a.tile_dirs, a.dir_end);
     const int M = a.n_mics, N = a.n_samples;                   // M % 16 == 0, N % 4 == 0, N <= 256 (plan_das)
+    const int n_half = M / HC;                                  // half chunks of 8 mics
     const float* __restrict__ sig0 = signals + (size_t)f0 * a.m_total * N;
     const float* __restrict__ sig1 = signals + (size_t)f1 * a.m_total * N;
     float* __restrict__ img0 = images + (size_t)f0 * a.image_stride;
     float* __restrict__ img1 = images + (size_t)f1 * a.image_stride;
     const int32_t* __restrict__ dig = reinterpret_cast<const int32_t*>(taps);   // the digest rides in the unused `taps` slot
 
-    // This wave stages the (mic, frame) pairs pr = wave + 16 i, i = 0, 1  <->  chunk mic pr >> 1, frame pr & 1.
-    // Lane c holds chunk c's mic id (first 64 chunks): the per-chunk prefetch is then one independent load.
-    int vmic[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int cm = (wave + W * i) >> 1;
-        vmic[i] = (lane < a.n_chunks) ? mics[lane * MC + cm] : 0;
-    }
-    auto fetch = [&](int ch, float4 (&st)[2]) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int pr = wave + W * i, cm = pr >> 1;
-            const int mic = (ch < kWave) ? __builtin_amdgcn_readlane(vmic[i], ch) : mics[ch * MC + cm];
-            const float* src = ((pr & 1) ? sig1 : sig0) + (size_t)mic * N;
-            st[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (4 * lane < N) st[i] = *reinterpret_cast<const float4*>(src + 4 * lane);
-        }
+    // The LDS image is the 16-mic chunk the digest was built for (mic m -> slot m % 16), used as TWO halves of 8 mics: while
+    // the waves sweep half h, each of them also writes its row of half h + 1 into the other half -- ONE barrier per 8 mics,
+    // and the staging stores (slow: 13 cycles per ds_write_b128 and wave on the LDS store path) run under other waves' adds
+    // instead of between two barriers with every SIMD idle.
+    // This wave stages row `wave` of every half: mic (wave >> 1) of the half, frame (wave & 1).
+    // Lane c holds half c's mic id (first 64 halves): the per-half prefetch is then one independent load.
+    const int vmic = (lane < n_half) ? mics[lane * HC + (wave >> 1)] : 0;
+    auto fetch = [&](int h) -> float4 {
+        const int mic = (h < kWave) ? __builtin_amdgcn_readlane(vmic, h) : mics[h * HC + (wave >> 1)];
+        const float* src = ((wave & 1) ? sig1 : sig0) + (size_t)mic * N;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (4 * lane < N) v = *reinterpret_cast<const float4*>(src + 4 * lane);
+        return v;
     };
-    auto stage = [&](const float4 (&st)[2]) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int pr = wave + W * i;
-            float* row0 = lds + pr * G::kSlot;                 // (cm * 2 + frame) * kSlot
-            const float4 v = st[i];
-            const float py = dpp_prev(v.y), pz = dpp_prev(v.z), pw = dpp_prev(v.w), nx = dpp_next(v.x);
-            write_copies<C>(row0, RS, LEAD, lane, v, py, pz, pw);
-            if constexpr (kLerp) {
-                // D[i] = s[i+1] - s[i], the reference's own subtraction (lerp_and_sum.c:54); D[-1] stays 0 (prefix)
-                const float4 dq = make_float4(v.y - v.x, v.z - v.y, v.w - v.z, nx - v.w);
-                const float dy = dpp_prev(dq.y), dz = dpp_prev(dq.z), dw = dpp_prev(dq.w);
-                write_copies<C>(row0 + C * RS, RS, LEAD, lane, dq, dy, dz, dw);
-            }
-            if (lane < (LEAD >> 2)) {                         // the zero prefix (also wiped by the parked rows of the previous group)
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int c = 0; c < C * A; ++c) reinterpret_cast<float4*>(row0 + c * RS)[lane] = z;
-            }
+    auto stage = [&](int h, const float4 v, bool wipe) {
+        float* row0 = lds + (((h & 1) * W) + wave) * G::kSlot;  // slot (h & 1) * 8 + (wave >> 1), frame wave & 1
+        const float py = dpp_prev(v.y), pz = dpp_prev(v.z), pw = dpp_prev(v.w), nx = dpp_next(v.x);
+        write_copies<C>(row0, RS, LEAD, lane, v, py, pz, pw);
+        if constexpr (kLerp) {
+            // D[i] = s[i+1] - s[i], the reference's own subtraction (lerp_and_sum.c:54); D[-1] stays 0 (prefix)
+            const float4 dq = make_float4(v.y - v.x, v.z - v.y, v.w - v.z, nx - v.w);
+            const float dy = dpp_prev(dq.y), dz = dpp_prev(dq.z), dw = dpp_prev(dq.w);
+            write_copies<C>(row0 + C * RS, RS, LEAD, lane, dq, dy, dz, dw);
+        }
+        if (wipe) {
+            // the zero prefix: nothing but the parked rows of the power pass ever overwrites it, so only a group's first
+            // visit of a half restores it -- one store: lane -> (copy row lane / 14, quad lane % 14) of the C * A rows
+            static_assert((LEAD >> 2) * C * A <= kWave, "one lane per prefix quad");
+            constexpr int PQ = LEAD >> 2;
+            if (lane < PQ * C * A) reinterpret_cast<float4*>(row0 + (lane / PQ) * RS)[lane % PQ] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
 
-    float4 staged[2];
-    fetch(0, staged);
+    float4 st = fetch(0);
     const int lb = 16 * lane + (int)(unsigned)(size_t)((__attribute__((address_space(3))) char*)lds);
+    BF_STAMP_DECL
 
     for (int g0 = tile_begin; g0 < tile_end; g0 += kGroup) {
         f32x2 acc[DW][2][2];
@@ -1718,23 +1728,31 @@ __global__ void __launch_bounds__(1024, 4) das_pair_kernel(BF_TABLE_PARAMS, KArg
 #pragma unroll
             for (int f = 0; f < 2; ++f) { acc[j][f][0] = f32x2{0.0f, 0.0f}; acc[j][f][1] = f32x2{0.0f, 0.0f}; }
 
-        for (int ch = 0; ch < a.n_chunks; ++ch) {
-            __syncthreads();   // every wave is done with the previous contents (chunk reads or parked rows)
-            stage(staged);
-            __syncthreads();
-            {   // request the next chunk (or the next group's first) while this one is consumed
-                int ng0 = g0, nch = ch + 1;
-                if (nch == a.n_chunks) { nch = 0; ng0 = g0 + kGroup; }
-                if (ng0 < tile_end) fetch(nch, staged);
+        BF_STAMP(7);
+        __syncthreads();   // the previous group's parked rows have been summed
+        BF_STAMP(1);
+        stage(0, st, true);
+        st = fetch(1);
+        BF_STAMP(2);
+        __syncthreads();
+        BF_STAMP(3);
+
+        for (int h = 0; h < n_half; ++h) {
+            if (h + 1 < n_half) {
+                stage(h + 1, st, h == 0);                       // into the half whose sweeps ended before the last barrier
+                // request what is staged an iteration from now: half h + 2, or the next group's first half (the same rows)
+                if (h + 2 < n_half) st = fetch(h + 2);
+                else if (g0 + kGroup < tile_end) st = fetch(0);
+                BF_STAMP(2);
             }
             const int dw0 = g0 + wave * DW;                     // wave-uniform
             if (dw0 < tile_end) {
                 const size_t grp = (size_t)(dw0 - a.dir_begin) / DW;
-                const int32_t* __restrict__ et = dig + (grp * M + (size_t)ch * MC) * DW;
-                const float* __restrict__ ht = reinterpret_cast<const float*>(dig) + a.digest_h_off + (grp * M + (size_t)ch * MC) * DW;
+                const int32_t* __restrict__ et = dig + (grp * M + (size_t)h * HC) * DW;
+                const float* __restrict__ ht = reinterpret_cast<const float*>(dig) + a.digest_h_off + (grp * M + (size_t)h * HC) * DW;
                 struct Entries { int e[DW]; unsigned long long hp[DW / 2]; };
                 auto request = [&](Entries& t, int m) {
-                    // (reads past the chunk's last mic stay inside the slack-padded table and are dropped)
+                    // (reads past the half's last mic stay inside the slack-padded table and are dropped)
 #pragma unroll
                     for (int j = 0; j < DW; ++j) t.e[j] = et[m * DW + j];
 #pragma unroll
@@ -1758,20 +1776,28 @@ __global__ void __launch_bounds__(1024, 4) das_pair_kernel(BF_TABLE_PARAMS, KArg
                     pair_steps<ALGO, 3>(acc, S0, D0, S1, D1, cur.e[5], cur.e[6], cur.e[7], cur.hp[3], lb);
                 };
                 using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+                static_assert(HC == 8, "eight mics: two trips of three and two more");
 #pragma unroll 1
-                for (int t = 0; t < MC / 3; ++t) {             // 16 mics: five trips of three and one more
+                for (int t = 0; t < 2; ++t) {
                     mic(0, I0{}); mic(1, I1{}); mic(2, I2{});
                     et += 3 * DW; ht += 3 * DW;
                 }
                 mic(0, I0{});
+                mic(1, I1{});
             }
+            BF_STAMP(0);       // sweep -> waiting for the others
+            __syncthreads();   // half h is free, half h + 1 is staged
+            BF_STAMP(h + 1 < n_half ? 3 : 4);
         }
 
         // ---- k-ordered mean power (pad_and_sum.c:120-128), one frame at a time: the 16 waves park the squared means of their
         // directions (row = direction; the rows alias the chunk buffer), then one direction per lane runs the sequential sum.
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            __syncthreads();
+            if (f == 1) {
+                __syncthreads();        // frame 0's rows have been summed
+                BF_STAMP(4);
+            }
             auto park = [&](auto mul_c) {
 #pragma unroll
                 for (int j = 0; j < DW; ++j) {
@@ -1789,7 +1815,9 @@ __global__ void __launch_bounds__(1024, 4) das_pair_kernel(BF_TABLE_PARAMS, KArg
                 }
             };
             if (__builtin_expect(a.n_is_pow2, 1)) park(std::true_type{}); else park(std::false_type{});
+            BF_STAMP(5);                // -> waiting
             __syncthreads();
+            BF_STAMP(6);                // -> ordered sum (two waves; the others go on to the next barrier)
             const int g = wave * kWave + lane;            // parked row of this lane
             const int d = g0 + g;
             if (g < kGroup && d < tile_end && (f == 0 || two)) {
@@ -1809,6 +1837,8 @@ __global__ void __launch_bounds__(1024, 4) das_pair_kernel(BF_TABLE_PARAMS, KArg
             }
         }
     }
+    BF_STAMP(7);
+    BF_STAMP_FLUSH;
 }
 #undef BF_P_ACC
 #undef BF_P_PAD_STEP
@@ -2068,10 +2098,10 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
         const size_t buf = slot_bytes * (size_t)mc * (size_t)p.nf;
         const size_t wave_rows = (size_t)dw * p.srow * sizeof(float);          // the parked rows of one wave
         p.lds_bytes = buf > 2 * wave_rows ? buf : 2 * wave_rows;
-        if (nseg == 1 && p.lds_bytes < waves * wave_rows) p.lds_bytes = waves * wave_rows;   // N <= 256: the whole group parks at once
+        if (nseg == 1 && p.lds_bytes < p.waves * wave_rows) p.lds_bytes = p.waves * wave_rows;   // N <= 256: the whole group parks at once
         int pw = (int)(p.lds_bytes / wave_rows);                                 // waves that park together (power of two)
         p.pbw = pw >= 16 ? 16 : pw >= 8 ? 8 : pw >= 4 ? 4 : 2;
-        if (p.pbw > waves) p.pbw = waves;
+        if (p.pbw > p.waves) p.pbw = p.waves;
     }
     if (p.layout != 2) {
         p.scratch_off = round_up(p.mic_chunk * p.row_stride, 4);
@@ -2105,14 +2135,16 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
         spread = (table_bytes <= ((size_t)3 << 20) && !(L.debug & 32)) || (L.debug & 64);   // debug bits 5 / 6: A/B switches (never / always)
         // an XCD's share of the table beyond its L2: all frames of a tile back to back (tile_and_frame); debug bit 7: never
         p.frame_inner = (!spread && p.layout == 2 && table_bytes > ((size_t)16 << 20) && wg_frames > 1 && !(L.debug & 128)) ? 1 : 0;
-        const int xcds = 8, cus_per_xcd = n_cus >= xcds ? n_cus / xcds : 1;
+        const int wg_per_cu = 1;
+        const int xcds = 8, cus_per_xcd = (n_cus >= xcds ? n_cus / xcds : 1) * wg_per_cu;
         long long best_cost = -1;
         int best_k = 4;
         for (int i = 0; i < 8; ++i) {
             const int k = i < 7 ? i + 2 : 1;
             const long long tiles = (dirs + (long long)k * group - 1) / ((long long)k * group);
             const long long tiles_x = tiles / xcds + (tiles % xcds ? 1 : 0);        // the busiest XCD's share
-            const long long rounds = spread ? (tiles * wg_frames + n_cus - 1) / n_cus : (tiles_x * wg_frames + cus_per_xcd - 1) / cus_per_xcd;
+            const long long slots = (long long)n_cus * wg_per_cu;
+            const long long rounds = spread ? (tiles * wg_frames + slots - 1) / slots : (tiles_x * wg_frames + cus_per_xcd - 1) / cus_per_xcd;
             const long long cost = rounds * k;
             if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_k = k; }
         }
@@ -2162,6 +2194,21 @@ hipError_t launch_digest(const DasLaunch& L, const DasPlan& plan, int32_t* d_dig
 long long digest_shareable_steps(const DasLaunch& L, const DasPlan& plan)
 {
     return plan.dpw > 1 ? grouped_entries(L, plan) / plan.dpw * (plan.dpw - 1) : 0;
+}
+
+// Profiling build only: read and clear the phase totals of das_pair_kernel (16 counters; zeros in a production build).
+hipError_t read_phase_stamps(unsigned long long* out16, bool clear)
+{
+#ifdef BF_STAMPS
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(copies::g_stamps), 16 * sizeof(unsigned long long));
+    if (e != hipSuccess || !clear) return e;
+    const unsigned long long zero[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(copies::g_stamps), zero, sizeof(zero));
+#else
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    (void)clear;
+    return hipSuccess;
+#endif
 }
 
 hipError_t launch_das(const DasLaunch& L, const DasPlan& plan, hipStream_t stream)

@@ -85,6 +85,8 @@ _sig("bf_clear_error", None)
 _sig("bf_gpu_available", C.c_int)
 _sig("bf_last_das_variant", C.c_int)
 _sig("bf_set_device", C.c_int, C.c_int)
+_sig("bf_set_debug", None, C.c_int)
+_sig("bf_read_phase_stamps", C.c_int, C.POINTER(C.c_ulonglong), C.c_int)
 _sig("bf_publish_frame", None, FP)
 _sig("bf_miso_listen_block", C.c_int, FP, C.c_float)
 _sig("bf_get_steer", C.c_int, IP)
