@@ -224,6 +224,12 @@ int bf_fd_mvdr_power_device(const float *d_lire_t, const float *d_liim_t, const 
  *       and the number kept.  K <= 4096. */
 int bf_yolo_decode_device(const void *const raw[3], const int h[3], const int w[3], const int strides[3], const float *anchors, int batch, int nc,
                           int is_half, float conf_thres, float *d_boxes, float *d_scores, int *d_cls, void *stream);
+/*   bf_topk_candidates_device: the k (<= 1024) best-scoring boxes of every image in descending score order (ties: lower box index
+ *       first) -- d_top_scores [batch][k], d_top_boxes [batch][k][4], d_top_cls [batch][k], d_counts [batch] = entries with a
+ *       positive score (decode marks rejected boxes with -1).  One workgroup per image: radix select, ordered tie admission,
+ *       bitonic sort in LDS.  This is the candidate list bf_nms_device walks. */
+int bf_topk_candidates_device(const float *d_scores, const float *d_boxes, const int *d_cls, int batch, int total, int k, float *d_top_scores,
+                              float *d_top_boxes, int *d_top_cls, int *d_counts, void *stream);
 int bf_nms_device(const float *d_boxes, const float *d_scores, const int *d_cls, const int *d_counts, int batch, int k, float iou_thres, int max_det,
                   unsigned long long *d_mask, float *d_out, int *d_out_count, void *stream);
 

@@ -86,3 +86,51 @@ def mvdr_power(frames, phase_shift, bin_lo, bin_hi, loading=1e-2):
         Ria = np.linalg.solve(R, a)
         out += (1.0 / np.real(np.sum(a.conj() * Ria, axis=0))).reshape(out.shape)
     return out
+
+
+# ---- the same two maps on a SHARD of the flat direction grid, without the [K, M, X, Y] phase table (at BASELINE config 5's
+# size -- 256 mics x 361 x 361 directions x 377 bins -- that table is 200 GB in complex128; one rank's 1/8 shard is processed
+# bin by bin instead).  Same arithmetic as tables() / das_power() / mvdr_power(): equal to them on the shard.
+
+def tables_dirs(dir_lo, dir_hi, n_samples=256, res_x=13, res_y=13, fs=48828, c=343.0, d=0.02, view_angle=68.0, z=1.0, aspect=16 / 9,
+                arrays=4, f_lo=0, f_hi=18000):
+    """-> dict(freq [K], bin_lo, bin_hi, g float64 [M, hi - lo] metres, c): calc_phase_shift_cartesian.py:17-45 for the flat
+    directions d = x * res_y + y in [dir_lo, dir_hi)."""
+    rp = r_prime_all(d, arrays=arrays)
+    x_max = z * np.tan(np.deg2rad(view_angle / 2))
+    y_max = x_max / aspect
+    xs_all = np.linspace(-x_max, x_max, res_x)
+    ys_all = np.linspace(-y_max, y_max, res_y)
+    flat = np.arange(dir_lo, dir_hi)
+    xs, ys = xs_all[flat // res_y], ys_all[flat % res_y]
+    r = np.sqrt(xs ** 2 + ys ** 2 + z ** 2)
+    f = np.linspace(0, int(int(fs) / 2), int(n_samples / 2) + 1)
+    lo = int((np.abs(f - f_lo)).argmin())
+    hi = int((np.abs(f - f_hi)).argmin())
+    g = (xs[None, :] * rp[0][:, None] + ys[None, :] * rp[1][:, None]) / r[None, :]
+    return dict(freq=f[lo:hi].copy(), bin_lo=lo, bin_hi=hi, g=g, c=c, x_scan=xs_all, y_scan=ys_all, r_prime_all=rp)
+
+
+def das_power_dirs(signal, t):
+    """das_power() on the shard described by tables_dirs(): signal float [N, M] -> float64 [hi - lo]."""
+    X = np.fft.rfft(signal, axis=0)[t["bin_lo"]:t["bin_hi"], :]
+    out = np.zeros(t["g"].shape[1])
+    for k, f in enumerate(t["freq"]):
+        phase = np.exp(1j * (-(2 * np.pi * f / t["c"]) * t["g"]))    # [M, D]
+        out += np.abs(X[k] @ phase) ** 2
+    return out
+
+
+def mvdr_power_dirs(frames, t, loading=1e-2):
+    """mvdr_power() on the shard described by tables_dirs(): frames float [F, N, M] -> float64 [hi - lo]."""
+    F, N, M = frames.shape
+    Xf = np.fft.rfft(frames, axis=1)[:, t["bin_lo"]:t["bin_hi"], :]
+    out = np.zeros(t["g"].shape[1])
+    for k, f in enumerate(t["freq"]):
+        x = Xf[:, k, :]
+        R = (x.T @ x.conj()) / F
+        R = R + loading * (np.trace(R).real / M) * np.eye(M)
+        a = np.exp(1j * ((2 * np.pi * f / t["c"]) * t["g"]))         # conj(phase_shift[k]): [M, D]
+        Ria = np.linalg.solve(R, a)
+        out += 1.0 / np.real(np.sum(a.conj() * Ria, axis=0))
+    return out

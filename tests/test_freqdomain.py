@@ -40,6 +40,18 @@ def _scene(t, ix, iy, n_frames, rng, M=64, N=256):
                      0.3 * rng.standard_normal((N, M)) for _ in range(n_frames)])
 
 
+def test_shard_oracle_equals_full_grid_oracle():
+    """tables_dirs / das_power_dirs / mvdr_power_dirs (bin by bin, no [K, M, X, Y] table) == the full-grid oracle on the shard."""
+    import freq_np as F
+    t = F.tables(res_x=9, res_y=7, arrays=1)
+    td = F.tables_dirs(10, 40, res_x=9, res_y=7, arrays=1)
+    frames = np.random.default_rng(1).standard_normal((70, 256, 64))
+    full = F.mvdr_power(frames, t["phase_shift"], t["bin_lo"], t["bin_hi"]).ravel()
+    assert np.max(np.abs(F.mvdr_power_dirs(frames, td) - full[10:40]) / full[10:40]) <= 1e-12
+    d = F.das_power(frames[0], t["phase_shift"], t["bin_lo"], t["bin_hi"]).ravel()
+    assert np.max(np.abs(F.das_power_dirs(frames[0], td) - d[10:40])) <= 1e-12 * d.max()
+
+
 def test_mvdr_oracle_properties():
     """Builder-defined MVDR: peak at the source, main lobe no wider than delay-and-sum on the same data."""
     import freq_np as F
@@ -93,6 +105,83 @@ def test_gpu_mvdr_matches_float64_oracle(native):
         assert np.max(np.abs(dgot - dwant)) <= TOL_OF_PEAK * dwant.max()
     finally:
         C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y = old
+
+
+def _with_config(**kw):
+    from realtime_scripts import config as C
+    old = {k: getattr(C, k) for k in kw}
+    for k, v in kw.items():
+        setattr(C, k, v)
+    return C, old
+
+
+@pytest.mark.gpu
+def test_gpu_config3_full_size_mvdr_and_das(native):
+    """BASELINE config 3 at its stated size: 64 mics, 256-sample windows, 101 x 101 directions -- MVDR (builder-defined) and
+    phase-steer delay-and-sum over the whole grid against the float64 oracle."""
+    import torch
+    import freq_np as F
+    from realtime_scripts import beam_forming_algorithm as B
+    C, old = _with_config(N_MICROPHONES=64, ACTIVE_ARRAYS=1, MAX_RES_X=101, MAX_RES_Y=101)
+    try:
+        fb = B.FrequencyBeamformer()
+        assert (fb.M, fb.D, fb.K) == (64, 101 * 101, 94)
+        t = F.tables_dirs(0, 101 * 101, res_x=101, res_y=101, arrays=1)
+        ix, iy = 70, 33
+        frames = _scene(t, ix, iy, 190, np.random.default_rng(31)).astype(np.float32)
+        want = F.mvdr_power_dirs(frames.astype(np.float64), t, loading=1e-2)
+        d_frames = torch.from_numpy(np.ascontiguousarray(frames.transpose(0, 2, 1))).cuda()      # [F, M, N] mic-major
+        got = fb.mvdr_power(d_frames, loading=1e-2).double().cpu().numpy()
+        assert np.argmax(got) == np.argmax(want) == ix * 101 + iy
+        assert np.max(np.abs(got - want) / want) <= 2e-4
+        dwant = np.stack([F.das_power_dirs(fr, t) for fr in frames[:4].astype(np.float64)])
+        dgot = fb.das_power(d_frames[:4].contiguous()).double().cpu().numpy()
+        assert np.max(np.abs(dgot - dwant)) <= TOL_OF_PEAK * dwant.max()
+    finally:
+        for k, v in old.items():
+            setattr(C, k, v)
+
+
+@pytest.mark.gpu
+def test_gpu_config5_one_rank_shard_mvdr_and_das(native):
+    """BASELINE config 5 at its stated size, as ONE of the 8 ranks sees it: 256 mics, 1024-sample windows (377 bins), the
+    rank's shard of the 361 x 361 grid (16,291 directions; the full steering table would be ~100 GB).  The GPU computes the whole
+    shard; the float64 oracle checks every 16th direction of it (the oracle's solves are what takes the time)."""
+    import torch
+    import freq_np as F
+    import multi_gpu
+    from realtime_scripts import beam_forming_algorithm as B
+    C, old = _with_config(N_MICROPHONES=256, ACTIVE_ARRAYS=4, MAX_RES_X=361, MAX_RES_Y=361, N_SAMPLES=1024)
+    try:
+        D = 361 * 361
+        lo, hi = multi_gpu.shard_range(D, 8, 3)
+        assert hi - lo == 16291
+        fb = B.FrequencyBeamformer(dir_range=(lo, hi))
+        assert (fb.M, fb.D, fb.D_full, fb.K) == (256, 16291, D, 377)
+        src = lo + 5000                                             # a source inside the shard, on a checked direction
+        pick = np.arange(lo + (src - lo) % 16, hi, 16)
+        t_src = F.tables_dirs(src, src + 1, n_samples=1024, res_x=361, res_y=361, arrays=4)
+        rng = np.random.default_rng(41)
+        tt = np.arange(1024) / 48828.0
+        tau = t_src["g"][:, 0] / 343.0
+        frames = np.stack([sum(np.sin(2 * np.pi * f * (tt[:, None] + tau[None, :]) + rng.uniform(0, 6.28)) for f in (2500.0, 5200.0, 8100.0)) +
+                           0.3 * rng.standard_normal((1024, 256)) for _ in range(320)]).astype(np.float32)
+        d_frames = torch.from_numpy(np.ascontiguousarray(frames.transpose(0, 2, 1))).cuda()      # [F, M, N] mic-major
+        got = fb.mvdr_power(d_frames, loading=1e-2).double().cpu().numpy()
+        dgot = fb.das_power(d_frames[:2].contiguous()).double().cpu().numpy()
+        del fb
+        # the oracle on the picked directions: g of those columns only
+        t = F.tables_dirs(lo, hi, n_samples=1024, res_x=361, res_y=361, arrays=4)
+        t["g"] = np.ascontiguousarray(t["g"][:, pick - lo])
+        want = F.mvdr_power_dirs(frames.astype(np.float64), t, loading=1e-2)
+        assert lo + int(np.argmax(got)) == src and pick[int(np.argmax(want))] == src
+        assert np.max(np.abs(got[pick - lo] - want) / want) <= 5e-4     # conditioning of R^-1 in float32 at 256 mics
+        dwant = np.stack([F.das_power_dirs(fr, t) for fr in frames[:2].astype(np.float64)])
+        assert np.max(np.abs(dgot[:, pick - lo] - dwant)) <= TOL_OF_PEAK * dwant.max()
+    finally:
+        for k, v in old.items():
+            setattr(C, k, v)
+        util.configure("cfg1")
 
 
 GEMM_SHAPES = [

@@ -1114,6 +1114,17 @@ int bf_yolo_decode_device(const void* const raw[3], const int h[3], const int w[
     return HIP_OK(bf::launch_yolo_decode(raw, h, w, strides, anchors, batch, nc, is_half, conf_thres, d_boxes, d_scores, d_cls, st)) ? 0 : -1;
 }
 
+int bf_topk_candidates_device(const float* d_scores, const float* d_boxes, const int* d_cls, int batch, int total, int k, float* d_top_scores,
+                              float* d_top_boxes, int* d_top_cls, int* d_counts, void* stream)
+{
+    std::lock_guard<std::mutex> lock(S().mu);
+    if (!d_scores || !d_boxes || !d_cls || !d_top_scores || !d_top_boxes || !d_top_cls || !d_counts) { set_error("bf_topk_candidates_device: null pointer"); return -1; }
+    if (k < 1 || k > 1024 || batch < 1 || total < 1) { set_error("bf_topk_candidates_device: batch %d, %d boxes, k = %d (1..1024)", batch, total, k); return -1; }
+    if (!ensure_device()) return -1;
+    return HIP_OK(bf::launch_topk_candidates(d_scores, d_boxes, d_cls, batch, total, k, d_top_scores, d_top_boxes, d_top_cls, d_counts,
+                                             reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
+}
+
 int bf_nms_device(const float* d_boxes, const float* d_scores, const int* d_cls, const int* d_counts, int batch, int k, float iou_thres, int max_det,
                   unsigned long long* d_mask, float* d_out, int* d_out_count, void* stream)
 {

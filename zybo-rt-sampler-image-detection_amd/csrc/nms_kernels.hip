@@ -108,7 +108,123 @@ __global__ void __launch_bounds__(64) nms_scan_kernel(const float* __restrict__ 
     if (lane == 0) out_count[b] = kept;
 }
 
+// ---- candidate selection: the K best-scoring boxes of every image, in descending score order (ties: lower box index first),
+// with their boxes and classes gathered -- what feeds the greedy pass.  One 1024-thread workgroup per image:
+//   1. radix select (four 8-bit passes over a monotone integer image of the float scores) finds the K-th largest score;
+//   2. boxes above it are compacted into LDS in any order, boxes equal to it are admitted in index order until K are in;
+//   3. a bitonic sort of the (score key, ~index) pairs in LDS orders them;
+//   4. scores / boxes / classes are gathered to the candidate arrays, counts[b] = candidates with a positive score.
+// K <= 1024.  No index ever leaves [0, T): slots beyond the image's boxes are emitted as score -1.
+__device__ __forceinline__ unsigned score_key(float x)
+{
+    unsigned u = __float_as_uint(x);
+    if (x != x) return 0u;                                       // NaN: below everything
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);           // monotone: a > b  <=>  key(a) > key(b)
+}
+
+__global__ void __launch_bounds__(1024) topk_select_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, const int* __restrict__ cls, int T,
+                                                           int K, float* __restrict__ top_scores, float* __restrict__ top_boxes, int* __restrict__ top_cls,
+                                                           int* __restrict__ counts)
+{
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long cand[1024];
+    __shared__ unsigned s_prefix, s_remaining, s_fill, s_running, s_wave_tot[16], s_positive;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* sc = scores + (size_t)b * T;
+    const int keff = min(K, T);
+    cand[tid] = 0ull;
+    if (tid == 0) { s_prefix = 0u; s_remaining = (unsigned)keff; s_fill = 0u; s_running = 0u; s_positive = 0u; }
+    __syncthreads();
+    unsigned mask = 0u;
+    for (int pass = 3; pass >= 0; --pass) {
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        for (int i = tid; i < T; i += 1024) {
+            const unsigned k = score_key(sc[i]);
+            if ((k & mask) == prefix) atomicAdd(&hist[(k >> (8 * pass)) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned rem = s_remaining, cum = 0u;
+            int bin = 255;
+            for (; bin > 0; --bin) {
+                if (cum + hist[bin] >= rem) break;
+                cum += hist[bin];
+            }
+            s_remaining = rem - cum;                             // how many of this bin's elements are still needed
+            s_prefix = prefix | ((unsigned)bin << (8 * pass));
+        }
+        mask |= 0xFFu << (8 * pass);
+        __syncthreads();
+    }
+    const unsigned kth = s_prefix, need_eq = s_remaining;       // the K-th largest key; how many boxes equal to it are admitted
+    // boxes above the K-th: any order
+    for (int i = tid; i < T; i += 1024) {
+        const unsigned k = score_key(sc[i]);
+        if (k > kth) {
+            const unsigned slot = atomicAdd(&s_fill, 1u);
+            cand[slot] = ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        }
+    }
+    __syncthreads();
+    // boxes equal to the K-th: the first `need_eq` in index order (a workgroup-wide ordered count per 1024 boxes)
+    const unsigned base_fill = s_fill;
+    for (int i0 = 0; i0 < T; i0 += 1024) {
+        if (s_running >= need_eq) break;                         // (uniform: s_running is read after the previous round's barrier)
+        const int i = i0 + tid;
+        const bool eq = i < T && score_key(sc[i]) == kth;
+        const unsigned long long bal = __ballot(eq);
+        if (lane == 0) s_wave_tot[wave] = (unsigned)__popcll(bal);
+        __syncthreads();
+        unsigned before = s_running;
+        for (int w = 0; w < wave; ++w) before += s_wave_tot[w];
+        const unsigned rank = before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+        if (eq && rank < need_eq) cand[base_fill + rank] = ((unsigned long long)kth << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        __syncthreads();
+        if (tid == 0) { unsigned tot = 0u; for (int w = 0; w < 16; ++w) tot += s_wave_tot[w]; s_running += tot; }
+        __syncthreads();
+    }
+    __syncthreads();
+    // bitonic sort, descending, of the 1024 pairs (empty slots are 0 = below every real pair: a real pair's low word is >= 1 only
+    // if its index is < 2^32 - 1, and its high word is >= 1 unless the score is NaN or -inf... both sort last together with the padding)
+    for (unsigned k2 = 2; k2 <= 1024; k2 <<= 1) {
+        for (unsigned j = k2 >> 1; j > 0; j >>= 1) {
+            const unsigned partner = tid ^ j;
+            if (partner > (unsigned)tid) {
+                const unsigned long long x = cand[tid], y = cand[partner];
+                const bool desc = (tid & k2) == 0;
+                if (desc ? x < y : x > y) { cand[tid] = y; cand[partner] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid < K) {
+        const unsigned long long c = cand[tid];
+        const bool real = tid < keff;
+        const unsigned idx = real ? 0xFFFFFFFFu - (unsigned)(c & 0xFFFFFFFFull) : 0u;
+        const bool ok = real && idx < (unsigned)T;
+        const float s = ok ? sc[idx] : -1.0f;
+        top_scores[(size_t)b * K + tid] = s;
+        const float4 bx = ok ? reinterpret_cast<const float4*>(boxes)[(size_t)b * T + idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4*>(top_boxes)[(size_t)b * K + tid] = bx;
+        top_cls[(size_t)b * K + tid] = ok ? cls[(size_t)b * T + idx] : 0;
+        if (s > 0.0f) atomicAdd(&s_positive, 1u);
+    }
+    __syncthreads();
+    if (tid == 0) counts[b] = (int)s_positive;
+}
+
 }  // namespace
+
+hipError_t launch_topk_candidates(const float* d_scores, const float* d_boxes, const int* d_cls, int batch, int total, int K, float* d_top_scores,
+                                  float* d_top_boxes, int* d_top_cls, int* d_counts, hipStream_t stream)
+{
+    if (K < 1 || K > 1024 || total < 1 || batch < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)batch), dim3(1024), 0, stream, d_scores, d_boxes, d_cls, total, K, d_top_scores, d_top_boxes,
+                       d_top_cls, d_counts);
+    return hipGetLastError();
+}
 
 hipError_t launch_yolo_decode(const void* const raw[3], const int hs[3], const int ws[3], const int strides[3], const float* anchors /*[3][3][2]*/,
                               int batch, int nc, int is_half, float conf_thres, float* d_boxes, float* d_scores, int* d_cls, hipStream_t stream)

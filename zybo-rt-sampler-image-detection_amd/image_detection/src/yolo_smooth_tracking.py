@@ -28,6 +28,7 @@ class Detector:
         if model_path is not None:
             self.net.load_state_dict(torch.load(model_path, map_location=device))
         self.anchors = np.ascontiguousarray(np.asarray(yolov5s.ANCHORS, dtype=np.float32).reshape(3, 3, 2))
+        self._ws = {}
 
     def preprocess(self, frames_u8):
         """uint8 [B, H, W, 3] (BGR as OpenCV delivers it, main.pyx:632) -> network input [B, 3, H, W] RGB in [0, 1], channels_last."""
@@ -48,21 +49,28 @@ class Detector:
         st = (C.c_int * 3)(*yolov5s.STRIDES)
         ptrs = (C.c_void_p * 3)(*[r.data_ptr() for r in raw])
         T = 3 * sum(int(r.shape[2]) * int(r.shape[3]) for r in raw)
-        boxes = t.empty((B, T, 4), dtype=t.float32, device=self.device)
-        scores = t.empty((B, T), dtype=t.float32, device=self.device)
-        cls = t.empty((B, T), dtype=t.int32, device=self.device)
+        K = min(MAX_NMS, T)
+        # Workspaces whose raw addresses go into the HIP kernels' arguments are allocated once per shape and kept: a captured
+        # graph then replays onto memory this object owns, whatever the caching allocator does between replays.
+        key = (B, T, K)
+        ws_ = self._ws.get(key)
+        if ws_ is None:
+            ws_ = self._ws[key] = dict(boxes=t.empty((B, T, 4), dtype=t.float32, device=self.device),
+                                       scores=t.empty((B, T), dtype=t.float32, device=self.device),
+                                       cls=t.empty((B, T), dtype=t.int32, device=self.device),
+                                       mask=t.empty((B, K, (K + 63) // 64), dtype=t.int64, device=self.device),
+                                       top=t.empty((B, K), dtype=t.float32, device=self.device), cb=t.empty((B, K, 4), dtype=t.float32, device=self.device),
+                                       cc=t.empty((B, K), dtype=t.int32, device=self.device), counts=t.empty((B,), dtype=t.int32, device=self.device))
+        boxes, scores, cls, mask = ws_["boxes"], ws_["scores"], ws_["cls"], ws_["mask"]
         s = t.cuda.current_stream().cuda_stream
         is_half = 1 if raw[0].dtype == t.float16 else 0
         if nat.lib.bf_yolo_decode_device(ptrs, hs, ws, st, nat.fptr(self.anchors), B, self.nc, is_half, conf_thres, boxes.data_ptr(),
                                          scores.data_ptr(), cls.data_ptr(), s) != 0:
             nat.check()
-        K = min(MAX_NMS, T)
-        top, idx = t.topk(scores, K, dim=1)                                 # library sort: candidate order for the greedy pass
-        counts = (top > 0).sum(dim=1).to(t.int32)
-        cb = t.gather(boxes, 1, idx.unsqueeze(-1).expand(-1, -1, 4)).contiguous()
-        cc = t.gather(cls, 1, idx).contiguous()
-        top = top.contiguous()
-        mask = t.empty((B, K, (K + 63) // 64), dtype=t.int64, device=self.device)
+        top, cb, cc, counts = ws_["top"], ws_["cb"], ws_["cc"], ws_["counts"]
+        if nat.lib.bf_topk_candidates_device(scores.data_ptr(), boxes.data_ptr(), cls.data_ptr(), B, T, K, top.data_ptr(), cb.data_ptr(), cc.data_ptr(),
+                                             counts.data_ptr(), s) != 0:        # candidate order for the greedy pass
+            nat.check()
         out = t.zeros((B, max_det, 6), dtype=t.float32, device=self.device)
         n_out = t.zeros((B,), dtype=t.int32, device=self.device)
         if nat.lib.bf_nms_device(cb.data_ptr(), top.data_ptr(), cc.data_ptr(), counts.data_ptr(), B, K, iou_thres, max_det, mask.data_ptr(),
