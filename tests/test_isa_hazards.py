@@ -1,17 +1,90 @@
-"""The hand-scheduled LDS reads of das_kernels.hip stay sound only while hipcc never copies a register that has a read in
-flight (scripts/dev/check_inflight_copies.py explains).  Compiles the kernels to gfx950 assembly (no GPU needed) and scans it."""
+"""The hand-scheduled LDS reads of das_kernels.hip stay sound only while nothing touches a register that has a read in
+flight (scripts/dev/check_inflight_copies.py explains).  CPU-only: compiles the kernels to gfx950 assembly, builds the control-
+flow graph of every das_copies_kernel / das_pair_kernel instantiation (out-of-line `.subsection 1` stubs and loop back-edges
+included), runs the in-flight data-flow over every path, and reads spill / scratch sizes from the code-object metadata."""
 import importlib.util
 import os
+
+import pytest
 
 import util
 
 
-def test_no_register_with_a_read_in_flight_is_copied(tmp_path):
+@pytest.fixture(scope="module")
+def chk():
     spec = importlib.util.spec_from_file_location("check_inflight_copies", os.path.join(util.ROOT, "scripts", "dev", "check_inflight_copies.py"))
-    chk = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(chk)
-    asm = str(tmp_path / "das_kernels.s")
-    chk.compile_asm(asm)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.fixture(scope="module")
+def asm(chk, tmp_path_factory):
+    path = str(tmp_path_factory.mktemp("isa") / "das_kernels.s")
+    chk.compile_asm(path)
+    return path
+
+
+FAKE = """
+_ZN2bf12_GLOBAL__N_16copies15das_pair_kernelILi9EEEvPKfPfPKiS7_S4_S4_NS0_5KArgsE:
+	s_load_dwordx2 s[0:1], s[4:5], 0x0
+	s_waitcnt lgkmcnt(0)
+	ds_read_b64 v[10:11], v1 offset:0
+%s
+	s_endpgm
+.Lfunc_end0:
+"""
+
+
+@pytest.mark.parametrize("body,n_bad", [
+    ("\ts_waitcnt lgkmcnt(0)\n\tv_pk_add_f32 v[2:3], v[2:3], v[10:11]", 0),                              # consumed after the wait
+    ("\tv_mov_b32_e32 v20, v11\n\ts_waitcnt lgkmcnt(0)", 1),                                              # copied while in flight
+    ("\tv_mov_b32_e32 v10, 0\n\ts_waitcnt lgkmcnt(0)", 1),                                                # overwritten while in flight
+    ("\tds_write_b64 v1, v[10:11]\n\ts_waitcnt lgkmcnt(0)", 1),                                           # stored while in flight
+    ("\tds_read_b64 v[12:13], v1 offset:8\n\ts_waitcnt lgkmcnt(1)\n\tv_mov_b32_e32 v20, v10\n\tv_mov_b32_e32 v21, v12\n\ts_waitcnt lgkmcnt(0)", 1),   # counted wait: the older read has landed, the younger not
+    # the hazard sits behind a branch, in an out-of-line stub that the straight-line text never reaches
+    ("\ts_cmp_lg_u32 s2, s3\n\ts_cbranch_scc1 .Lstub\n.Lback:\n\ts_waitcnt lgkmcnt(0)\n\tv_pk_add_f32 v[2:3], v[2:3], v[10:11]\n"
+     "\t.subsection 1\n.Lstub:\n\tv_add_u32_e32 v20, v10, v1\n\ts_waitcnt lgkmcnt(0)\n\ts_branch .Lback\n\t.subsection 0", 1),
+    # a wait inside the not-taken stub must not hide a read that is still in flight on the fall-through path
+    ("\ts_cbranch_scc1 .Lstub\n.Lback:\n\tv_mov_b32_e32 v20, v10\n\ts_waitcnt lgkmcnt(0)\n"
+     "\t.subsection 1\n.Lstub:\n\ts_waitcnt lgkmcnt(0)\n\ts_branch .Lback\n\t.subsection 0", 1),
+    # carried around a loop: in flight at the back-edge, touched at the loop head on the second trip
+    (".Lloop:\n\tv_mov_b32_e32 v20, v30\n\tds_read_b64 v[30:31], v1 offset:16\n\ts_add_u32 s2, s2, 1\n\ts_cmp_lt_u32 s2, 4\n\ts_cbranch_scc1 .Lloop\n\ts_waitcnt lgkmcnt(0)", 1),
+])
+def test_scanner_finds_what_it_should(chk, tmp_path, body, n_bad):
+    p = tmp_path / "fake.s"
+    p.write_text(FAKE % body)
+    kernels, bad = chk.scan(str(p))
+    assert kernels == 1 and len(bad) == n_bad, bad
+
+
+def test_no_register_with_a_read_in_flight_is_touched(chk, asm):
     kernels, bad = chk.scan(asm)
-    assert kernels >= 30           # every das_copies_kernel / das_pair_kernel instantiation
+    assert kernels >= 30
     assert not bad, bad[:5]
+
+
+def test_every_launchable_instantiation_is_scanned_and_none_that_pipelines_reads_spills(chk, asm):
+    """launch_nc (das_kernels.hip) can pick: the pair kernel (pad, lerp); the one-frame sweep for 1 / 2 / 4 segments with the fixed or
+    the run-time row stride, 16 waves -- one segment also with 8 waves -- and its direction-outer (DIRECT) twin; the three 8-tap FIR
+    flavours.  The instantiations that keep LDS reads in flight across asm statements (pair kernel; one-segment sweep) must not
+    use scratch: a spilled register with a read in flight is reloaded before the data lands."""
+    md = chk.metadata(asm)
+    names = [n for n in md if "das_copies_kernel" in n or "das_pair_kernel" in n]
+    short = dict(zip(chk.demangle(names), names))
+    want = ["bf::copies::das_pair_kernel<%d>" % a for a in (0, 1)]
+    for a in (0, 1):
+        want += ["bf::copies::das_copies_kernel<%d, 1, %d, %d, %s>" % (a, rs, w, d) for rs in (312, 0) for w, d in ((16, "false"), (8, "false"), (16, "true"))]
+        want += ["bf::copies::das_copies_kernel<%d, %d, %d, 16, %s>" % (a, seg, rs, d) for seg, fixed in ((2, 576), (4, 1088)) for rs in (fixed, 0) for d in ("false", "true")]
+    want += ["bf::copies::das_copies_kernel<%d, 1, %d, 16, false>" % (a, rs) for a in (2, 3, 4) for rs in (320, 0)]
+    missing = [w for w in want if w not in short]
+    assert not missing, missing
+    kernels, _ = chk.scan(asm)
+    assert kernels == len(names)                       # the scan covered every one of them
+    pipelined = [w for w in want if "das_pair_kernel" in w or (w.startswith("bf::copies::das_copies_kernel<0, 1,") or w.startswith("bf::copies::das_copies_kernel<1, 1,"))
+                 and w.endswith("false>")]
+    assert len(pipelined) == 2 + 2 * 4
+    for w in pipelined:
+        m = md[short[w]]
+        assert m["spill"] == 0 and m["scratch"] == 0, (w, m)
+        assert m["vgprs"] <= 128                        # 16 waves per CU
