@@ -34,6 +34,7 @@ WORKLOADS = {
     "cfg5": (256, 4, 1024, 361, 361, 8),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+VALU_PEAK_TLANEOPS = 78.65     # MI355X_MICROARCH.md: 157.3 TFLOP/s FP32 vector (spec) = 256 CUs x 4 SIMD-32 x 2.4 GHz lane-ops/s
 
 
 def algorithmic_bytes_per_frame(algo, M, N, D, T):
@@ -281,11 +282,15 @@ def main():
             dist.all_gather_into_tensor(out, d_part[b].cpu())
             d_full[b].copy_(out)
 
-    def beamform(k):
+    def release(k):
         b = k % nbuf
         if pending[b] is not None:
             pending[b].wait()          # the gather that last read this buffer (stream-level wait, the host runs on)
             pending[b] = None
+
+    def beamform(k):
+        b = k % nbuf
+        release(k)
         rc = nat.lib.bf_das_device(algo_id, d_sig.data_ptr(), M, d_part[b].data_ptr(), shard_cap, frames_global, nat.iptr(mics), M,
                                    lo, hi, stream.cuda_stream)
         if rc != 0:
@@ -310,7 +315,9 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        # HIP events on the launch stream bracket the beamforming kernel only (not the collective)
+        # HIP events on the launch stream bracket the beamforming kernel only: neither the collective nor the wait for
+        # the previous gather of this buffer
+        release(k)
         ev[k][0].record(stream)
         beamform(k)
         ev[k][1].record(stream)
@@ -344,17 +351,23 @@ def main():
         alg_bytes = frames_global * (sig_bytes + (bytes_frame - sig_bytes) * share)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         macs = frames_global * (hi - lo) * M * N
-        # The honest limiter is the VALU: per (direction, mic, 256-sample segment) step a wave issues 2 v_pk_add_f32 (pad),
-        # 2 v_pk_fma_f32 + 2 v_pk_add_f32 (lerp) or 32 v_fmac_f32 (8-tap FIR) plus a scalar compare/branch.  Floors measured
-        # with scripts/dev/valu_probe.hip on MI355X (16 waves per CU, ns per step per CU): the instruction mix alone.
+        # The binding resource is the fp32 VALU, not HBM: per (direction, mic, sample) the kernels execute
+        # 1 lane-op (pad: add), 2 (lerp: fma + add), 8 (8-tap FIRs: fma chain; 15 in the AVX summation order).  Peak: the guide's
+        # 157.3 TFLOP/s FP32 vector = 78.65 T lane-ops/s at 2.4 GHz (an FMA lane-op counts two flops there).
+        lane_ops = macs * {"pad": 1, "lerp": 2, "hybrid": 8, "fir_naive": 8, "fir_vec": 15}[args.algo]
+        valu_achieved = lane_ops / (kernel_ms * 1e-3) / 1e12
+        # ... and against what the instruction mix alone sustains on the chip (scripts/dev/valu_probe.hip / gen_issue_probe.py,
+        # 16 waves per CU, ns per (direction, mic, 256-sample segment) step per CU)
         steps = frames_global * (hi - lo) * M * ((N + 255) // 256)
         floor_ns = {"pad": 1.12, "lerp": 2.12}.get(args.algo, 32 * 1.18 / 4)
         step_ns = kernel_ms * 1e6 * 256 / steps              # 256 CUs
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             rec = json.load(open(tpath)).get("%s_%s_f%d_n%d" % (args.workload, args.algo, args.frames, world))
-            traffic = rec["hbm_bytes_per_launch"] if rec else None
+            if rec:
+                traffic = rec["hbm_bytes_per_launch"]
+                traffic_source = "stored, not measured in this run: profiles/traffic.json <- " + rec.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")
         line = {
             "metric": "beam-steered frames/sec (64 mics x 256 samples x 101x101 angles)" if args.workload == "cfg2" else "beam-steered frames/sec",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -364,17 +377,18 @@ def main():
                                    % (args.workload, M, N, X, Y, args.algo, args.frames),
                        "frames_per_step_global": frames_global, "directions_per_gpu": hi - lo,
                        "parallelism": "directions sharded over %d GPU(s) + RCCL all-gather of the heat-maps" % world if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": {5: "copies::das_pair_kernel<%s>", 2: "copies::das_copies_kernel<%s>", 3: "copies::das_copies_kernel<%s, DIRECT>",
-                                                        4: "copies::das_copies_kernel<%s>"}.get(nat.lib.bf_last_das_variant(), "das_mimo_kernel<%s>") % args.algo,
-                         "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "gather-accumulate kernel: tables stay L2-resident across the frames of a launch, sample quads are re-read "
-                                 "from LDS only when a direction's delay differs from its neighbour's; the binding resource is VALU issue, "
-                                 "not HBM (DESIGN.md section 5)",
-                         "valu": {"ns_per_step_per_cu": step_ns, "floor_ns_per_step_per_cu": floor_ns, "frac": floor_ns / step_ns,
-                                  "floor": "instruction mix alone at 16 waves/CU, scripts/dev/valu_probe.hip"},
-                         "gmacs_per_s": macs / (kernel_ms * 1e-3) / 1e9},
+            "roofline": {"bound": "valu", "achieved": valu_achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s (fp32; peak = 157.3 TFLOP/s / 2)",
+                         "frac": valu_achieved / VALU_PEAK_TLANEOPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": {5: "copies::das_pair_kernel<%s>", 2: "copies::das_copies_kernel<%s>", 3: "copies::das_copies_kernel<%s, DIRECT>",
+                                    4: "copies::das_copies_kernel<%s>", 6: "copies::das_long_kernel<%s>"}.get(nat.lib.bf_last_das_variant(), "das_mimo_kernel<%s>") % args.algo,
+                         "kernel_ms": kernel_ms, "gmacs_per_s": macs / (kernel_ms * 1e-3) / 1e9,
+                         "note": "gather-accumulate kernel, no MFMA: tables stay L2-resident across the frames of a launch and sample quads are "
+                                 "re-read from LDS only when a direction's delay differs from its neighbour's, so HBM is nearly idle and the "
+                                 "fp32 VALU binds (DESIGN.md section 5)",
+                         "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_launch": alg_bytes, "traffic": traffic, "traffic_source": traffic_source},
+                         "valu_probe": {"ns_per_step_per_cu": step_ns, "floor_ns_per_step_per_cu": floor_ns, "frac_of_probe_floor": floor_ns / step_ns,
+                                        "floor": "the step's packed instructions alone at 16 waves/CU and the clock the chip holds under that load"}},
         }
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line

@@ -152,6 +152,10 @@ EDGE = [
     (8,     8,  258,  2,  2,  8,  10.0),   # second segment almost empty, N not a multiple of 4 (scalar staging loads)
     (12,    9,  450,  3,  3,  8, 200.0),   # delays past the fixed-stride prefix: run-time row stride, partial chunk
     (40,   33, 1024,  3,  2,  8, 300.0),   # four segments, several chunks (pad stages two (mic, segment) pairs per wave)
+    (48,   24, 1024,  5,  4,  8,  40.0),   # das_long_kernel: four segments, six halves of 4 mics, n not a power of two (true division)
+    (32,   16,  512,  9,  8,  8,  60.0),   # das_long_kernel: two segments, 72 directions = one partial wave group
+    (16,   16, 1000,  3,  3,  8, 300.0),   # long rows with delays past the fixed prefix: run-time row stride (pad: long kernel; lerp: its LDS image does not fit -> das_copies_kernel)
+    (64,   64,  700, 17, 16,  8,  20.0),   # das_long_kernel: N not a multiple of 256 (third segment partial), 272 directions = five wave groups of 64
 ]
 
 

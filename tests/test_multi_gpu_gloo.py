@@ -72,3 +72,31 @@ def test_shard_ranges_cover_the_grid():
             assert spans[0][0] == 0 and spans[-1][1] == D
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert all(0 <= hi - lo <= cap for lo, hi in spans)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_over_gloo_keeps_the_json_contract():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), rehearsed on ONE card with
+    BF_BENCH_BACKEND=gloo (host-staged gather): the JSON line's multi-GPU bookkeeping -- n_gpus, the global batch (weak
+    scaling: per-GPU frames fixed), the direction shard per GPU -- and the shard self-check bench.py runs after its timed region.
+    The RCCL path itself needs two GPUs; this box has one."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BF_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "16"]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                          # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["config"]["frames_per_step_global"] == 32 and d["config"]["directions_per_gpu"] == 5101
+    assert d["unit"] == "frames/s" and d["value"] > 0 and abs(d["value"] - 32 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert d["roofline"]["bound"] == "valu" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["hbm"]["peak"] == 8000.0
+    assert "cpu_baseline" not in d                                  # rank 0 at N = 1 only

@@ -891,6 +891,57 @@ __device__ __forceinline__ void await_quads(Quad (&S)[NSEG], Quad (&D)[NSEG])
         asm volatile("" : BF_S_OPS(0), BF_D_OPS(0), BF_S_OPS(1), BF_D_OPS(1), BF_S_OPS(2), BF_D_OPS(2), BF_S_OPS(3), BF_D_OPS(3));
     }
 }
+// The same two helpers for the CONFLICT-FREE lane mapping of das_long_kernel: lane l owns the sample pairs 2l, 2l+1 and
+// 128 + 2l, 128 + 2l + 1 of every 256-sample segment, so that each ds_read_b64 covers 512 contiguous bytes (64 banks, no lane
+// pair on the same bank; with the 16-byte lane stride above every ds_read_b64 is a two-way conflict: SQ_LDS_BANK_CONFLICT).
+// Segment s: low pair at byte 1024 s + 8 l, high pair 512 bytes further.
+template <int NSEG, bool LERP>
+__device__ __forceinline__ void reload_quads_cf(Quad (&S)[NSEG], Quad (&D)[NSEG], int e, int ep, int lbase, int d_off)
+{
+    int ad, ad2;
+    static_assert(NSEG == 2 || NSEG == 4, "long rows: 2 or 4 segments");
+    if constexpr (NSEG == 2 && !LERP) {
+        asm volatile(BF_RELOAD_HEAD "v_add_u32 %[ad], %[e], %[lb]\n\t" BF_RD(0, 0, 512) BF_RD(1, 1024, 1536) BF_RELOAD_TAIL
+                     : BF_S_OPS(0), BF_S_OPS(1), [ad] "=&v"(ad) : [e] "s"(e), [ep] "s"(ep), [lb] "v"(lbase) : "scc");
+    } else if constexpr (NSEG == 2 && LERP) {
+        asm volatile(BF_RELOAD_HEAD "v_add_u32 %[ad], %[e], %[lb]\n\tv_add_u32 %[ad2], %[ad], %[doff]\n\t" BF_RD(0, 0, 512)
+                         BF_RDD(0, 0, 512) BF_RD(1, 1024, 1536) BF_RDD(1, 1024, 1536) BF_RELOAD_TAIL
+                     : BF_S_OPS(0), BF_D_OPS(0), BF_S_OPS(1), BF_D_OPS(1), [ad] "=&v"(ad), [ad2] "=&v"(ad2)
+                     : [e] "s"(e), [ep] "s"(ep), [lb] "v"(lbase), [doff] "s"(d_off) : "scc");
+    } else if constexpr (NSEG == 4 && !LERP) {
+        asm volatile(BF_RELOAD_HEAD "v_add_u32 %[ad], %[e], %[lb]\n\t" BF_RD(0, 0, 512) BF_RD(1, 1024, 1536) BF_RD(2, 2048, 2560)
+                         BF_RD(3, 3072, 3584) BF_RELOAD_TAIL
+                     : BF_S_OPS(0), BF_S_OPS(1), BF_S_OPS(2), BF_S_OPS(3), [ad] "=&v"(ad) : [e] "s"(e), [ep] "s"(ep), [lb] "v"(lbase) : "scc");
+    } else {
+        asm volatile(BF_RELOAD_HEAD "v_add_u32 %[ad], %[e], %[lb]\n\tv_add_u32 %[ad2], %[ad], %[doff]\n\t" BF_RD(0, 0, 512)
+                         BF_RDD(0, 0, 512) BF_RD(1, 1024, 1536) BF_RDD(1, 1024, 1536) BF_RD(2, 2048, 2560) BF_RDD(2, 2048, 2560) BF_RD(3, 3072, 3584) BF_RDD(3, 3072, 3584)
+                     BF_RELOAD_TAIL
+                     : BF_S_OPS(0), BF_D_OPS(0), BF_S_OPS(1), BF_D_OPS(1), BF_S_OPS(2), BF_D_OPS(2), BF_S_OPS(3), BF_D_OPS(3), [ad] "=&v"(ad), [ad2] "=&v"(ad2)
+                     : [e] "s"(e), [ep] "s"(ep), [lb] "v"(lbase), [doff] "s"(d_off) : "scc");
+    }
+}
+// (issue and wait in ONE statement: a mic's first quads, read in place)
+template <int NSEG, bool LERP>
+__device__ __forceinline__ void load_quads_cf(Quad (&S)[NSEG], Quad (&D)[NSEG], int e, int lbase, int d_off)
+{
+    int ad, ad2;
+    if constexpr (NSEG == 2 && !LERP) {
+        asm volatile("v_add_u32 %[ad], %[e], %[lb]\n\t" BF_RD(0, 0, 512) BF_RD(1, 1024, 1536) "s_waitcnt lgkmcnt(0)"
+                     : BF_S_OPS(0), BF_S_OPS(1), [ad] "=&v"(ad) : [e] "s"(e), [lb] "v"(lbase));
+    } else if constexpr (NSEG == 2 && LERP) {
+        asm volatile("v_add_u32 %[ad], %[e], %[lb]\n\tv_add_u32 %[ad2], %[ad], %[doff]\n\t" BF_RD(0, 0, 512) BF_RDD(0, 0, 512) BF_RD(1, 1024, 1536)
+                         BF_RDD(1, 1024, 1536) "s_waitcnt lgkmcnt(0)"
+                     : BF_S_OPS(0), BF_D_OPS(0), BF_S_OPS(1), BF_D_OPS(1), [ad] "=&v"(ad), [ad2] "=&v"(ad2) : [e] "s"(e), [lb] "v"(lbase), [doff] "s"(d_off));
+    } else if constexpr (NSEG == 4 && !LERP) {
+        asm volatile("v_add_u32 %[ad], %[e], %[lb]\n\t" BF_RD(0, 0, 512) BF_RD(1, 1024, 1536) BF_RD(2, 2048, 2560) BF_RD(3, 3072, 3584) "s_waitcnt lgkmcnt(0)"
+                     : BF_S_OPS(0), BF_S_OPS(1), BF_S_OPS(2), BF_S_OPS(3), [ad] "=&v"(ad) : [e] "s"(e), [lb] "v"(lbase));
+    } else {
+        asm volatile("v_add_u32 %[ad], %[e], %[lb]\n\tv_add_u32 %[ad2], %[ad], %[doff]\n\t" BF_RD(0, 0, 512) BF_RDD(0, 0, 512) BF_RD(1, 1024, 1536)
+                         BF_RDD(1, 1024, 1536) BF_RD(2, 2048, 2560) BF_RDD(2, 2048, 2560) BF_RD(3, 3072, 3584) BF_RDD(3, 3072, 3584) "s_waitcnt lgkmcnt(0)"
+                     : BF_S_OPS(0), BF_D_OPS(0), BF_S_OPS(1), BF_D_OPS(1), BF_S_OPS(2), BF_D_OPS(2), BF_S_OPS(3), BF_D_OPS(3), [ad] "=&v"(ad), [ad2] "=&v"(ad2)
+                     : [e] "s"(e), [lb] "v"(lbase), [doff] "s"(d_off));
+    }
+}
 #undef BF_RD
 #undef BF_RELOAD_HEAD
 #undef BF_RELOAD_TAIL
@@ -1849,6 +1900,254 @@ __global__ void __launch_bounds__(1024, 4) das_pair_kernel(BF_TABLE_PARAMS, KArg
 #undef BF_P_CHECK
 #undef BF_P_STUB
 
+// ==================================================================================================
+// Long blocks: pad / lerp at 256 < N <= 1024 (2 or 4 segments of 256 samples per row; BASELINE config 5: 256 mics x 1024).
+//
+// The sweep of das_copies_kernel with the chunk handling of das_pair_kernel and a conflict-free lane mapping:
+//   * a wave carries DW = 8 / 4 directions x NSEG = 2 / 4 segments (64 accumulator registers); per direction step the offset
+//     test is shared by 4 NSEG (lerp) packed operations;
+//   * the LDS image holds 2 halves of HC = 16 / NSEG mics; while the waves sweep one half each of them stages ONE (mic, segment)
+//     pair of the next half into the other -- one barrier per HC mics (the old kernel: two per 4 mics, staging between them with
+//     every SIMD idle), and the table-entry pipeline runs on across the barrier;
+//   * lane l owns the sample pairs (2l, 2l+1) and (128+2l, 128+2l+1) of a segment: every ds_read_b64 covers 512 contiguous bytes;
+//   * nothing is in flight across statements the compiler cannot see (a mic's first quads are read in place), and the kernel
+//     must not use scratch (tests/test_isa_hazards.py reads the code-object metadata).
+// Mic order and operation order are the reference's; the power is summed in k order from parked rows: bit-identical maps.
+template <int ALGO, int NSEG>
+struct LongGeo {
+    static constexpr bool kLerp = ALGO == ALGO_LERP;
+    static constexpr int kA = kLerp ? 2 : 1, kC = 2, kDw = Geo<NSEG>::kDw, kHalf = 16 / NSEG, kMc = 2 * kHalf;
+    static constexpr int kPark = Geo<NSEG>::kPark;
+};
+
+template <int ALGO, int NSEG, int RS>
+__global__ void __launch_bounds__(1024, 4) das_long_kernel(BF_TABLE_PARAMS, KArgs a)
+{
+    using G = LongGeo<ALGO, NSEG>;
+    constexpr bool kLerp = G::kLerp;
+    constexpr int A = G::kA, C = G::kC, HC = G::kHalf, W = 16, DW = G::kDw, kGroup = DW * W, kPark = G::kPark;
+    static_assert(RS == 0 || RS == Geo<NSEG>::kRs, "fixed row stride");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane_ = threadIdx.x & (kWave - 1), lane = lane_;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int tile, frame;
+    tile_and_frame(a, &tile, &frame);
+    const int tile_begin = a.dir_begin + tile * a.tile_dirs;
+    if (tile_begin >= a.dir_end) return;
+    const int tile_end = min(tile_begin + a.tile_dirs, a.dir_end);
+    const int rs = RS > 0 ? RS : a.row_stride, lead = RS > 0 ? Geo<NSEG>::kLead : a.lead;
+    const int M = a.n_mics, N = a.n_samples;                   // M % HC == 0 (plan_das)
+    const int n_half = M / HC;
+    const float* __restrict__ frame_sig = signals + (size_t)frame * a.m_total * N;
+    float* __restrict__ img = images + (size_t)frame * a.image_stride;
+    const int32_t* __restrict__ dig = reinterpret_cast<const int32_t*>(taps);   // the digest rides in the unused `taps` slot
+    const int slot_floats = A * C * rs;                        // floats per staged mic
+
+    // This wave stages the pair `wave` of every half: mic (wave / NSEG) of the half, segment (wave % NSEG).
+    const int my_mic = wave / NSEG, my_seg = wave % NSEG;
+    const int vmic = (lane < n_half) ? mics[lane * HC + my_mic] : 0;          // lane c: half c's mic id (first 64 halves)
+    // (`lane` passes through an empty asm in fetch / stage: their per-lane addresses are then recomputed where they are used --
+    //  a handful of integer operations per half -- instead of being hoisted out of the mic loop into registers the sweep needs)
+    auto fetch = [&](int h) -> Staged {
+        Staged st;
+        int lane = lane_;
+        asm volatile("" : "+v"(lane));
+        const int mic = (h < kWave) ? __builtin_amdgcn_readlane(vmic, h) : mics[h * HC + my_mic];
+        const float* src = frame_sig + (size_t)mic * N;
+        const int k = 4 * (64 * my_seg + lane);
+        st.v = make_float4(0.f, 0.f, 0.f, 0.f);
+        st.edge = 0.0f;
+        if ((N & 3) == 0) {
+            if (k < N) st.v = *reinterpret_cast<const float4*>(src + k);
+        } else {
+            if (k < N) st.v.x = src[k];
+            if (k + 1 < N) st.v.y = src[k + 1];
+            if (k + 2 < N) st.v.z = src[k + 2];
+            if (k + 3 < N) st.v.w = src[k + 3];
+        }
+        // what DPP cannot reach: the three samples before the segment and the one after it
+        const int ke = lane < 3 ? 256 * my_seg - 3 + lane : 256 * my_seg + 256;
+        if ((lane < 3 || lane == 63) && ke >= 0 && ke < N) st.edge = src[ke];
+        return st;
+    };
+    auto stage = [&](int h, const Staged& st, bool wipe) {
+        int lane = lane_;
+        asm volatile("" : "+v"(lane));
+        float* row0 = lds + ((h & 1) * HC + my_mic) * slot_floats;
+        const int col = lead + 256 * my_seg;
+        const float4 v = st.v;
+        float py = dpp_prev(v.y), pz = dpp_prev(v.z), pw = dpp_prev(v.w), nx = dpp_next(v.x);
+        const float ey = lane_value(st.edge, 0), ez = lane_value(st.edge, 1), ew = lane_value(st.edge, 2), en = lane_value(st.edge, 63);
+        if (lane == 0) { py = ey; pz = ez; pw = ew; }
+        if (lane == 63) nx = en;
+        write_copies<C>(row0, rs, col, lane, v, py, pz, pw);
+        if constexpr (kLerp) {
+            // D[i] = s[i+1] - s[i], the reference's own subtraction (lerp_and_sum.c:54); D[-1] stays 0 (prefix)
+            const float4 dq = make_float4(v.y - v.x, v.z - v.y, v.w - v.z, nx - v.w);
+            float dy = dpp_prev(dq.y), dz = dpp_prev(dq.z), dw = dpp_prev(dq.w);
+            if (lane == 0 && my_seg > 0) { dy = ez - ey; dz = ew - ez; dw = v.x - ew; }
+            write_copies<C>(row0 + C * rs, rs, col, lane, dq, dy, dz, dw);
+        }
+        if (wipe && my_seg == 0) {
+            // the zero prefix: only the parked rows of the power pass ever overwrite it -- restored on a group's first visit of a half
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = lane; q < (lead >> 2); q += kWave) {
+#pragma unroll
+                for (int c = 0; c < C * A; ++c) reinterpret_cast<float4*>(row0 + c * rs)[q] = z;
+            }
+        }
+    };
+
+    Staged st = fetch(0);
+    const int lb = 8 * lane + (int)(unsigned)(size_t)((__attribute__((address_space(3))) char*)lds);
+    const int d_off = 4 * C * rs;                               // D copies sit C rows after the s copies
+
+    for (int g0 = tile_begin; g0 < tile_end; g0 += kGroup) {
+        f32x2 acc[DW][NSEG][2];
+#pragma unroll
+        for (int j = 0; j < DW; ++j)
+#pragma unroll
+            for (int sg = 0; sg < NSEG; ++sg) { acc[j][sg][0] = f32x2{0.0f, 0.0f}; acc[j][sg][1] = f32x2{0.0f, 0.0f}; }
+
+        __syncthreads();   // the previous group's parked rows have been summed
+        stage(0, st, true);
+        st = fetch(1 % n_half);
+        const int dw0 = g0 + wave * DW;                         // wave-uniform
+        const bool busy = dw0 < tile_end;                       // this wave has directions in the tile
+        const size_t grp = busy ? (size_t)(dw0 - a.dir_begin) / DW : 0;
+        const int32_t* __restrict__ et = dig + grp * M * DW;
+        const float* __restrict__ ht = reinterpret_cast<const float*>(dig) + a.digest_h_off + grp * M * DW;
+        struct Entries { int e[DW]; unsigned long long hp[DW / 2]; };
+        auto request = [&](Entries& t, int m) {
+            // (reads past the last mic stay inside the slack-padded table and are dropped)
+#pragma unroll
+            for (int j = 0; j < DW; ++j) t.e[j] = et[m * DW + j];
+#pragma unroll
+            for (int j = 0; j < DW / 2; ++j) {
+                t.hp[j] = 0;
+                if constexpr (kLerp) t.hp[j] = *reinterpret_cast<const unsigned long long*>(ht + m * DW + 2 * j);
+            }
+        };
+        // table entries two mics ahead, three sets in rotation; the pipeline runs on across the halves' barriers
+        Entries E[3];
+        request(E[0], 0);
+        request(E[1], 1);
+        __syncthreads();
+
+        for (int h = 0; h < n_half; ++h) {
+            if (h + 1 < n_half) {
+                stage(h + 1, st, h == 0);                       // into the half whose sweeps ended before the last barrier
+                if (h + 2 < n_half) st = fetch(h + 2);
+                else if (g0 + kGroup < tile_end) st = fetch(0);
+            }
+            if (busy) {
+                Quad S[NSEG], Dq[NSEG];
+#pragma unroll
+                for (int sg = 0; sg < NSEG; ++sg) S[sg].lo = S[sg].hi = Dq[sg].lo = Dq[sg].hi = f32x2{0.0f, 0.0f};
+                auto mic = [&](int m, auto kc) {
+                    constexpr int K = decltype(kc)::value, K2 = (K + 2) % 3;
+                    const Entries& cur = E[K];
+                    __builtin_amdgcn_s_waitcnt(0xC07F);         // this mic's entries (requested two mics ago) have landed
+                    load_quads_cf<NSEG, kLerp>(S, Dq, cur.e[0], lb, d_off);
+                    request(E[K2], m + 2);                      // after the reads' wait, so that it does not sit on these loads
+                    auto stepj = [&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        if constexpr (j > 0) reload_quads_cf<NSEG, kLerp>(S, Dq, cur.e[j], cur.e[j - 1], lb, d_off);
+#pragma unroll
+                        for (int sg = 0; sg < NSEG; ++sg) {
+                            if constexpr (ALGO == ALGO_PAD) add_quad(acc[j][sg], S[sg]);
+                            else lerp_quad<j & 1>(acc[j][sg], S[sg], Dq[sg], cur.hp[j / 2]);
+                        }
+                    };
+                    stepj(std::integral_constant<int, 0>{});
+                    stepj(std::integral_constant<int, 1>{});
+                    stepj(std::integral_constant<int, 2>{});
+                    stepj(std::integral_constant<int, 3>{});
+                    if constexpr (DW == 8) {
+                        stepj(std::integral_constant<int, 4>{});
+                        stepj(std::integral_constant<int, 5>{});
+                        stepj(std::integral_constant<int, 6>{});
+                        stepj(std::integral_constant<int, 7>{});
+                    }
+                };
+                using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+                const int m0 = h * HC;
+                // HC mics: entry sets rotate K = m % 3 from 0 at the start of every half ...
+                mic(m0 + 0, I0{}); mic(m0 + 1, I1{}); mic(m0 + 2, I2{}); mic(m0 + 3, I0{});
+                if constexpr (HC == 8) { mic(m0 + 4, I1{}); mic(m0 + 5, I2{}); mic(m0 + 6, I0{}); mic(m0 + 7, I1{}); }
+                // ... so the two sets already requested for the next half's first mics move to slots 0 and 1 (scalar moves)
+                if constexpr (HC == 4) { E[0] = E[1]; E[1] = E[2]; }                      // mics m0 + 4, m0 + 5 sit in sets (4 % 3, 5 % 3) = (1, 2)
+                else { const Entries t = E[0]; E[0] = E[2]; E[1] = t; }                  // mics m0 + 8, m0 + 9 sit in sets (8 % 3, 9 % 3) = (2, 0)
+            }
+            __syncthreads();   // half h is free, half h + 1 is staged
+        }
+
+        // ---- k-ordered mean power (pad_and_sum.c:120-128): a.pbw waves at a time park the squared means of their directions
+        // (row = direction, k in order; the rows alias the LDS image), then one direction per lane runs the sequential sum.
+        // The squares replace the accumulators IN PLACE first: computed inside the rounds they are loop-invariant, and the
+        // compiler hoists all 64 of them out of the loop -- into scratch.
+        {
+            auto square = [&](auto mul_c) __attribute__((always_inline)) {   // (a call would force the accumulators into memory)
+#pragma unroll
+                for (int j = 0; j < DW; ++j) {
+#pragma unroll
+                    for (int sg = 0; sg < NSEG; ++sg) {
+                        // mean over the mics: a power-of-two count multiplies (exact), anything else divides like the reference
+                        const f32x2 a0 = acc[j][sg][0], a1 = acc[j][sg][1];
+                        float o0, o1, o2, o3;
+                        if constexpr (decltype(mul_c)::value) {
+                            o0 = a0.x * a.inv_n; o1 = a0.y * a.inv_n; o2 = a1.x * a.inv_n; o3 = a1.y * a.inv_n;
+                        } else {
+                            float fm = (float)M;
+                            asm volatile("" : "+v"(fm));   // not speculatable: keeps this path behind its branch
+                            o0 = a0.x / fm; o1 = a0.y / fm; o2 = a1.x / fm; o3 = a1.y / fm;
+                            __builtin_amdgcn_sched_barrier(0);   // one quad's divisions at a time: interleaved, their temporaries spill
+                        }
+                        acc[j][sg][0] = f32x2{o0 * o0, o1 * o1};
+                        acc[j][sg][1] = f32x2{o2 * o2, o3 * o3};
+                    }
+                }
+            };
+            if (__builtin_expect(a.n_is_pow2, 1)) square(std::true_type{}); else square(std::false_type{});
+        }
+        const int pw_waves = a.pbw;
+        for (int w0 = 0; w0 < W; w0 += pw_waves) {
+            if (w0 > 0) __syncthreads();                        // the previous round's rows have been summed
+            if (wave >= w0 && wave < w0 + pw_waves) {
+#pragma unroll
+                for (int j = 0; j < DW; ++j) {
+                    float* row = lds + ((wave - w0) * DW + j) * kPark;
+#pragma unroll
+                    for (int sg = 0; sg < NSEG; ++sg) {
+                        // samples (2l, 2l+1) and (128+2l, 128+2l+1) of the segment
+                        const f32x2 a0 = acc[j][sg][0], a1 = acc[j][sg][1];
+                        reinterpret_cast<float2*>(row + 256 * sg)[lane] = make_float2(a0.x, a0.y);
+                        reinterpret_cast<float2*>(row + 256 * sg + 128)[lane] = make_float2(a1.x, a1.y);
+                    }
+                }
+            }
+            __syncthreads();
+            const int g = wave * kWave + lane;                  // parked row of this lane
+            const int d = g0 + w0 * DW + g;
+            if (g < pw_waves * DW && d < tile_end) {
+                const float* row = lds + g * kPark;
+                const float4* row4 = reinterpret_cast<const float4*>(row);
+                float sum = 0.0f;
+                int k = 0;
+                for (; k + 32 <= N; k += 32) {
+                    float4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = row4[(k >> 2) + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { sum += v[u].x; sum += v[u].y; sum += v[u].z; sum += v[u].w; }
+                }
+                for (; k < N; ++k) sum += row[k];
+                img[d - a.image_origin] = sum / (float)N;
+            }
+        }
+    }
+}
+
 }  // namespace copies
 
 template <int ALGO, int NC>
@@ -1888,6 +2187,21 @@ hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, in
                     if (pair_scratch != 0) return hipErrorInvalidDeviceFunction;
                     const dim3 pair_grid((unsigned)plan.n_tiles * (unsigned)((frames + 1) / 2));
                     hipLaunchKernelGGL(kernel, pair_grid, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole, L.tab.frac,
+                                       reinterpret_cast<const float*>(L.tab.digest), a);
+                    return hipGetLastError();
+                }
+            }
+            if constexpr (!kFir && (NSEG == 2 || NSEG == 4)) {
+                if (plan.long_rows) {                           // das_long_kernel
+                    using LG = copies::LongGeo<ALGO, NSEG>;
+                    if (L.tab.digest == nullptr || L.tab.digest_direct || plan.waves != copies::kWaves || plan.mic_chunk != LG::kMc ||
+                        (L.n_mics % LG::kHalf) != 0 || plan.dpw != LG::kDw)
+                        return hipErrorInvalidValue;
+                    const bool fixed_rs = plan.row_stride == copies::Geo<NSEG>::kRs && plan.lead == copies::Geo<NSEG>::kLead;
+                    auto kernel = fixed_rs ? copies::das_long_kernel<ALGO, NSEG, copies::Geo<NSEG>::kRs> : copies::das_long_kernel<ALGO, NSEG, 0>;
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
+                    if (e != hipSuccess) return e;
+                    hipLaunchKernelGGL(kernel, grid, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole, L.tab.frac,
                                        reinterpret_cast<const float*>(L.tab.digest), a);
                     return hipGetLastError();
                 }
@@ -2092,12 +2406,23 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
             p.nf = 2;
             mc = 16;
         }
+        // Long rows (2 / 4 segments): das_long_kernel where its LDS image -- two halves of 16 / nseg mics -- fits and the mic count is
+        // a whole number of halves.  (debug bit 12: A/B switch back to das_copies_kernel)
+        p.long_rows = 0;
+        if (plain && nseg > 1 && !L.tab.digest_direct && !(L.debug & 4096)) {
+            const int half = 16 / nseg;
+            if ((L.n_mics % half) == 0 && slot_bytes * (size_t)(2 * half) <= (size_t)160 * 1024) {
+                p.long_rows = 1;
+                mc = 2 * half;
+            }
+        }
         p.mic_chunk = mc; p.n_chunks = (L.n_mics + mc - 1) / mc;
         p.waves = waves; p.dpw = dw; p.srow = nseg * 256 + 4;
         p.scratch_off = 0;
         const size_t buf = slot_bytes * (size_t)mc * (size_t)p.nf;
         const size_t wave_rows = (size_t)dw * p.srow * sizeof(float);          // the parked rows of one wave
         p.lds_bytes = buf > 2 * wave_rows ? buf : 2 * wave_rows;
+        if (p.long_rows && p.lds_bytes < 8 * wave_rows) p.lds_bytes = 8 * wave_rows;             // eight waves park together (two rounds)
         if (nseg == 1 && p.lds_bytes < p.waves * wave_rows) p.lds_bytes = p.waves * wave_rows;   // N <= 256: the whole group parks at once
         int pw = (int)(p.lds_bytes / wave_rows);                                 // waves that park together (power of two)
         p.pbw = pw >= 16 ? 16 : pw >= 8 ? 8 : pw >= 4 ? 4 : 2;
