@@ -19,7 +19,7 @@ usage: python scripts/dev/check_inflight_copies.py [file.s]     (without a file:
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-KERNEL_RE = re.compile(r"^(_ZN2bf\S*(das_copies_kernel|das_pair_kernel|das_long_kernel)\S*):")
+KERNEL_RE = re.compile(r"^(_ZN2bf\S*(das_copies_kernel|das_pair_kernel|das_long_kernel|das_hybrid_pair_kernel)\S*):")
 MAX_QUEUE = 24          # lgkmcnt is a 4-bit counter; older entries than this cannot be told apart by any wait
 
 
@@ -206,7 +206,7 @@ if __name__ == "__main__":
     for b in bad[:20]:
         print("REGISTER WITH A READ IN FLIGHT TOUCHED: %s line %d: %s" % b)
     md = metadata(path)
-    names = [n for n in md if "das_copies_kernel" in n or "das_pair_kernel" in n or "das_long_kernel" in n]
+    names = [n for n in md if "das_copies_kernel" in n or "das_pair_kernel" in n or "das_long_kernel" in n or "das_hybrid_pair_kernel" in n]
     for n, d in zip(names, demangle(names)):
         if md[n]["spill"] or md[n]["scratch"]:
             print("SPILLS: %-60s vgprs %3d spill %d scratch %d" % (d, md[n]["vgprs"], md[n]["spill"], md[n]["scratch"]))

@@ -60,7 +60,7 @@ def test_scanner_finds_what_it_should(chk, tmp_path, body, n_bad):
 
 def test_no_register_with_a_read_in_flight_is_touched(chk, asm):
     kernels, bad = chk.scan(asm)
-    assert kernels >= 38
+    assert kernels >= 39
     assert not bad, bad[:5]
 
 
@@ -70,7 +70,7 @@ def test_every_launchable_instantiation_is_scanned_and_none_that_pipelines_reads
     flavours.  The instantiations that keep LDS reads in flight across asm statements (pair kernel; one-segment sweep) must not
     use scratch: a spilled register with a read in flight is reloaded before the data lands."""
     md = chk.metadata(asm)
-    names = [n for n in md if "das_copies_kernel" in n or "das_pair_kernel" in n or "das_long_kernel" in n]
+    names = [n for n in md if "das_copies_kernel" in n or "das_pair_kernel" in n or "das_long_kernel" in n or "das_hybrid_pair_kernel" in n]
     short = dict(zip(chk.demangle(names), names))
     want = ["bf::copies::das_pair_kernel<%d>" % a for a in (0, 1)]
     for a in (0, 1):
@@ -78,11 +78,12 @@ def test_every_launchable_instantiation_is_scanned_and_none_that_pipelines_reads
         want += ["bf::copies::das_copies_kernel<%d, %d, %d, 16, %s>" % (a, seg, rs, d) for seg, fixed in ((2, 576), (4, 1088)) for rs in (fixed, 0) for d in ("false", "true")]
     want += ["bf::copies::das_copies_kernel<%d, 1, %d, 16, false>" % (a, rs) for a in (2, 3, 4) for rs in (320, 0)]
     want += ["bf::copies::das_long_kernel<%d, %d, %d>" % (a, seg, rs) for a in (0, 1) for seg, fixed in ((2, 576), (4, 1088)) for rs in (fixed, 0)]
+    want += ["bf::copies::das_hybrid_pair_kernel"]
     missing = [w for w in want if w not in short]
     assert not missing, missing
     kernels, _ = chk.scan(asm)
     assert kernels == len(names)                       # the scan covered every one of them
-    pipelined = [w for w in want if "das_pair_kernel" in w or (w.startswith("bf::copies::das_copies_kernel<0, 1,") or w.startswith("bf::copies::das_copies_kernel<1, 1,"))
+    pipelined = [w for w in want if "bf::copies::das_pair_kernel" in w or (w.startswith("bf::copies::das_copies_kernel<0, 1,") or w.startswith("bf::copies::das_copies_kernel<1, 1,"))
                  and w.endswith("false>")]
     assert len(pipelined) == 2 + 2 * 4
     for w in pipelined:

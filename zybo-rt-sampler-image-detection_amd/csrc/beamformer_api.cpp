@@ -323,12 +323,13 @@ bool ensure_digest(TableSet& t, bf::DasLaunch& L, bf::DasPlan& plan, hipStream_t
         State& s = S();
         if (!HIP_OK(t.digest.reserve(bf::digest_elements(L, plan))) || !HIP_OK(s.d_counter.reserve(1))) return false;
         t.digest_direct = false;
-        const bool grouped = L.algo == bf::ALGO_PAD || L.algo == bf::ALGO_LERP;
+        const bool plain = L.algo == bf::ALGO_PAD || L.algo == bf::ALGO_LERP;
+        const bool grouped = plain || (L.algo == bf::ALGO_HYBRID && plan.nf == 2);
         if (grouped && !HIP_OK(hipMemsetAsync(s.d_counter.p, 0, sizeof(unsigned long long), stream))) return false;
         if (!HIP_OK(bf::launch_digest(L, plan, t.digest.p, grouped ? s.d_counter.p : nullptr, false, stream))) return false;
         // once per (table, layout): wait, so that a later launch on ANOTHER stream cannot overtake the digest's construction
         if (!HIP_OK(hipStreamSynchronize(stream))) return false;
-        if (grouped && plan.waves == 16) {
+        if (plain && plan.waves == 16) {
             // A table without structure (more than half of the direction steps change the delay) defeats the sweep: use the
             // direction-outer kernel variant and its [D][M] digest instead.
             unsigned long long reloads = 0;
@@ -348,7 +349,7 @@ bool ensure_digest(TableSet& t, bf::DasLaunch& L, bf::DasPlan& plan, hipStream_t
     }
     L.tab.digest_direct = t.digest_direct;
     L.tab.digest = t.digest.p;
-    S().last_variant = (L.algo == bf::ALGO_PAD || L.algo == bf::ALGO_LERP) ? (t.digest_direct ? 3 : plan.nf == 2 ? 5 : plan.long_rows ? 6 : 2) : 4;
+    S().last_variant = (L.algo == bf::ALGO_PAD || L.algo == bf::ALGO_LERP) ? (t.digest_direct ? 3 : plan.nf == 2 ? 5 : plan.long_rows ? 6 : 2) : plan.nf == 2 ? 7 : 4;
     return true;
 }
 

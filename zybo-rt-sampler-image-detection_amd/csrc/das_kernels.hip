@@ -672,7 +672,7 @@ __global__ void __launch_bounds__(256) digest_kernel(const int32_t* __restrict__
 __global__ void __launch_bounds__(256) digest_grouped_kernel(const int32_t* __restrict__ whole, const float* __restrict__ frac, int32_t* __restrict__ digest,
                                                              long long entries, long long h_off, int n_mics, int gdirs, int dir_begin, int dir_end,
                                                              int mic_chunk, int arrays, int row_stride, int lead, int bias, int ncopies,
-                                                             unsigned long long* __restrict__ reload_count)
+                                                             unsigned long long* __restrict__ reload_count, int pack_guards)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < entries; i += (long long)gridDim.x * blockDim.x) {
         const int j = (int)(i % gdirs);
@@ -683,8 +683,15 @@ __global__ void __launch_bounds__(256) digest_grouped_kernel(const int32_t* __re
         if (d > dir_end - 1) d = dir_end - 1;
         const int m = mic % mic_chunk;
         const int pd = whole[d * n_mics + mic] + bias;
-        digest[i] = ((m * arrays * ncopies + (pd & (ncopies - 1))) * row_stride + lead - (pd & ~(ncopies - 1))) * 4;
+        // (pack_guards = the hybrid pair kernel: rows hold two frames interleaved, a sample is two floats wide)
+        digest[i] = ((m * arrays * ncopies + (pd & (ncopies - 1))) * row_stride + (pack_guards ? 2 : 1) * (lead - (pd & ~(ncopies - 1)))) * 4;
         if (frac != nullptr) reinterpret_cast<float*>(digest)[h_off + i] = frac[d * n_mics + mic];
+        if (pack_guards) {
+            // hybrid: output j of a lane (sample 4 lane + j) is live for 4 lane + j > p, i.e. from lane n_j = (p + 4 - j) >> 2 on;
+            // the four n_j, one byte each (hybrid_convolve_and_sum.c:58: the loop starts at i = 0, i.e. sample p + 1)
+            const int p = whole[d * n_mics + mic];
+            digest[h_off + i] = ((p + 4) >> 2) | (((p + 3) >> 2) << 8) | (((p + 2) >> 2) << 16) | (((p + 1) >> 2) << 24);
+        }
         if (reload_count != nullptr && j > 0) {
             // how often the sweep will have to re-read: this direction's delay differs from the previous direction's
             // (directions past the end repeat the last one: never a change)
@@ -1901,6 +1908,302 @@ __global__ void __launch_bounds__(1024, 4) das_pair_kernel(BF_TABLE_PARAMS, KArg
 #undef BF_P_STUB
 
 // ==================================================================================================
+// Hybrid beamformer (integer delay + 8-tap fractional FIR, hybrid_convolve_and_sum.c:51-121), two frames per workgroup.
+//
+// das_copies_kernel<hybrid> walks direction-outer: per (direction, mic) three ds_read_b128, two tap loads and the guard masks for
+// 32 v_fmac_f32 -- and a plain (unpacked) VALU instruction holds its SIMD as long as a packed one (scripts/dev/fmac_probe.hip:
+// v_fmac_f32 sustains 47 % of the fp32 peak, v_pk_fma_f32 91 %, even as one dependent chain).  Here:
+//   * the two frames of a workgroup are INTERLEAVED sample by sample in the LDS rows (f0 s0, f1 s0, f0 s1, f1 s1, ..), so a
+//     window read lands as register pairs (frame 0, frame 1) and every multiply-accumulate is a v_pk_fma_f32 with the tap as
+//     its scalar operand: 32 packed instructions per (direction, mic) for both frames' 64 multiply-accumulates;
+//   * the WINDOW a (direction, mic) reads depends on the whole-sample delay only, which neighbouring directions mostly share
+//     (the structure the pad / lerp sweep lives on), only the taps differ: mic-outer sweep over the wave's 8 directions, the
+//     11-sample windows re-read only when the LDS offset changes (scalar test, out-of-line stub);
+//   * the 8 taps of a step arrive in SGPRs (s_load_dwordx8 two steps ahead); the guard ("output k receives nothing for k <= p")
+//     is four EXEC masks, rebuilt only together with the window;
+//   * interleaved rows need only TWO shifted copies for 16-byte-aligned window reads (the window start must fall on an even
+//     sample), so the LDS image holds 32 mics: two halves of 16, staged under the sweep as in das_pair_kernel.
+// Operation order per output is the reference's (taps 0..7 in order, mics in order): bit-identical maps.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct HybridGeo {
+    static constexpr int kC = 2, kLead = Geo<1>::kLead, kRs = 2 * Geo<1>::kRsFir;   // floats per row: two frames interleaved
+    static constexpr int kHalf = 16, kMc = 2 * kHalf;
+    static constexpr int kSlot = kC * kRs;               // floats per staged mic (both frames)
+};
+
+// The guard of a (direction, mic): output j of a lane (sample 4 lane + j) is live on the lanes n_j .. 63 (four bytes of `ng`,
+// digest_grouped_kernel; n < 64 under the fixed row stride).  It depends on the whole-sample delay only -- like the window.
+struct HybridMasks { unsigned long long m[4]; };
+#define BF_H_MASKS                                                                                          \
+    "s_lshl_b64 %[m0], -1, %[ng]\n\t"                                                                       \
+    "s_lshr_b32 %[t], %[ng], 8\n\ts_lshl_b64 %[m1], -1, %[t]\n\t"                                            \
+    "s_lshr_b32 %[t], %[ng], 16\n\ts_lshl_b64 %[m2], -1, %[t]\n\t"                                           \
+    "s_lshr_b32 %[t], %[ng], 24\n\ts_lshl_b64 %[m3], -1, %[t]\n\t"
+#define BF_H_READS                                                                                          \
+    "ds_read_b128 %[q0], %[ad] offset:0\n\tds_read_b128 %[q1], %[ad] offset:16\n\tds_read_b128 %[q2], %[ad] offset:32\n\t" \
+    "ds_read_b128 %[q3], %[ad] offset:48\n\tds_read_b128 %[q4], %[ad] offset:64\n\tds_read_b128 %[q5], %[ad] offset:80\n\t"
+#define BF_H_QOPS [q0] "+v"(Q[0]), [q1] "+v"(Q[1]), [q2] "+v"(Q[2]), [q3] "+v"(Q[3]), [q4] "+v"(Q[4]), [q5] "+v"(Q[5])
+// (re)read the window (11 samples x 2 frames + 1 = 6 quads) for LDS byte offset ec unless it equals ep
+__device__ __forceinline__ void hybrid_window(f32x4 (&Q)[6], HybridMasks& k, int ep, int ec, int ng, int lbase)
+{
+    int ad, t;
+    asm volatile("s_cmp_lg_u32 %[ec], %[ep]\n\ts_cbranch_scc1 .Lr_%=\n.Lb_%=:\n\t"
+                 ".subsection 1\n.Lr_%=:\n\tv_add_u32 %[ad], %[ec], %[lb]\n\t" BF_H_READS BF_H_MASKS
+                 "s_waitcnt lgkmcnt(0)\n\ts_branch .Lb_%=\n\t.subsection 0"
+                 : BF_H_QOPS, [ad] "=&v"(ad), [m0] "+s"(k.m[0]), [m1] "+s"(k.m[1]), [m2] "+s"(k.m[2]), [m3] "+s"(k.m[3]), [t] "=&s"(t)
+                 : [ep] "s"(ep), [ec] "s"(ec), [ng] "s"(ng), [lb] "v"(lbase)
+                 : "scc");
+}
+// a mic's first window: read in place (no test)
+__device__ __forceinline__ void hybrid_window_first(f32x4 (&Q)[6], HybridMasks& k, int ec, int ng, int lbase)
+{
+    int ad, t;
+    asm volatile("v_add_u32 %[ad], %[ec], %[lb]\n\t" BF_H_READS BF_H_MASKS "s_waitcnt lgkmcnt(0)"
+                 : BF_H_QOPS, [ad] "=&v"(ad), [m0] "=&s"(k.m[0]), [m1] "=&s"(k.m[1]), [m2] "=&s"(k.m[2]), [m3] "=&s"(k.m[3]), [t] "=&s"(t)
+                 : [ec] "s"(ec), [ng] "s"(ng), [lb] "v"(lbase)
+                 : "scc");
+}
+#undef BF_H_MASKS
+#undef BF_H_READS
+#undef BF_H_QOPS
+
+// One (direction, mic) step for both frames: output j of a lane takes o_j = fma(h_t, W[j + t], o_j), t = 0..7 in order
+// (hybrid_convolve_and_sum.c:58-63) under the guard mask of output j; o_j and W[.] are (frame 0, frame 1) pairs, the taps come
+// as four aligned SGPR pairs (even tap: low half for both lanes, odd tap: high half).
+#define BF_H_E(j, hh, w) "v_pk_fma_f32 %[o" #j "], %[" #hh "], %[w" #w "], %[o" #j "] op_sel_hi:[0,1,1]\n\t"
+#define BF_H_O(j, hh, w) "v_pk_fma_f32 %[o" #j "], %[" #hh "], %[w" #w "], %[o" #j "] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+#define BF_H_OUT(j, w0, w1, w2, w3, w4, w5, w6, w7)                                                          \
+    BF_H_E(j, h01, w0) BF_H_O(j, h01, w1) BF_H_E(j, h23, w2) BF_H_O(j, h23, w3) BF_H_E(j, h45, w4) BF_H_O(j, h45, w5) BF_H_E(j, h67, w6) BF_H_O(j, h67, w7)
+__device__ __forceinline__ void hybrid_step(f32x2 (&o)[4], const f32x4 (&Q)[6], const unsigned long long (&h)[4], const HybridMasks& k)
+{
+    unsigned long long saved;
+    // W[t] = (frame 0, frame 1) of the window's sample t: the two halves of the quads
+    const f32x2 w0 = __builtin_shufflevector(Q[0], Q[0], 0, 1), w1 = __builtin_shufflevector(Q[0], Q[0], 2, 3);
+    const f32x2 w2 = __builtin_shufflevector(Q[1], Q[1], 0, 1), w3 = __builtin_shufflevector(Q[1], Q[1], 2, 3);
+    const f32x2 w4 = __builtin_shufflevector(Q[2], Q[2], 0, 1), w5 = __builtin_shufflevector(Q[2], Q[2], 2, 3);
+    const f32x2 w6 = __builtin_shufflevector(Q[3], Q[3], 0, 1), w7 = __builtin_shufflevector(Q[3], Q[3], 2, 3);
+    const f32x2 w8 = __builtin_shufflevector(Q[4], Q[4], 0, 1), w9 = __builtin_shufflevector(Q[4], Q[4], 2, 3);
+    const f32x2 w10 = __builtin_shufflevector(Q[5], Q[5], 0, 1);
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[m0]\n\t"
+        BF_H_OUT(0, 0, 1, 2, 3, 4, 5, 6, 7)
+        "s_mov_b64 exec, %[m1]\n\t"
+        BF_H_OUT(1, 1, 2, 3, 4, 5, 6, 7, 8)
+        "s_mov_b64 exec, %[m2]\n\t"
+        BF_H_OUT(2, 2, 3, 4, 5, 6, 7, 8, 9)
+        "s_mov_b64 exec, %[m3]\n\t"
+        BF_H_OUT(3, 3, 4, 5, 6, 7, 8, 9, 10)
+        "s_mov_b64 exec, %[sv]"
+        : [o0] "+v"(o[0]), [o1] "+v"(o[1]), [o2] "+v"(o[2]), [o3] "+v"(o[3]), [sv] "=&s"(saved)
+        : [h01] "s"(h[0]), [h23] "s"(h[1]), [h45] "s"(h[2]), [h67] "s"(h[3]), [m0] "s"(k.m[0]), [m1] "s"(k.m[1]), [m2] "s"(k.m[2]), [m3] "s"(k.m[3]),
+          [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3), [w4] "v"(w4), [w5] "v"(w5), [w6] "v"(w6), [w7] "v"(w7), [w8] "v"(w8), [w9] "v"(w9),
+          [w10] "v"(w10));
+}
+#undef BF_H_OUT
+#undef BF_H_E
+#undef BF_H_O
+
+__global__ void __launch_bounds__(1024, 4) das_hybrid_pair_kernel(BF_TABLE_PARAMS, KArgs a)
+{
+    using G = HybridGeo;
+    constexpr int C = G::kC, RS = G::kRs, LEAD = G::kLead, HC = G::kHalf, W = 16, DW = 8, kGroup = DW * W, kPark = Geo<1>::kPark;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int tile, fpair;
+    tile_and_frame(a, &tile, &fpair);
+    const int f0 = 2 * fpair;
+    const bool two = f0 + 1 < a.n_frames;                      // an odd frame count: the last workgroup row computes its frame twice
+    const int f1 = two ? f0 + 1 : f0;
+    const int tile_begin = a.dir_begin + tile * a.tile_dirs;
+    if (tile_begin >= a.dir_end) return;
+    const int tile_end = min(tile_begin + a.tile_dirs, a.dir_end);
+    const int M = a.n_mics, N = a.n_samples;                   // M % 16 == 0, N % 4 == 0, N <= 256, 8 taps (plan_das)
+    const int n_half = M / HC;
+    const float* __restrict__ sig0 = signals + (size_t)f0 * a.m_total * N;
+    const float* __restrict__ sig1 = signals + (size_t)f1 * a.m_total * N;
+    float* __restrict__ img0 = images + (size_t)f0 * a.image_stride;
+    float* __restrict__ img1 = images + (size_t)f1 * a.image_stride;
+    const int32_t* __restrict__ dig = reinterpret_cast<const int32_t*>(frac);   // the digest rides in the `frac` slot (hybrid has no weights)
+
+    // staging: wave w stages mic w of every half, both frames.  Lane c holds half c's mic id (first 64 halves).
+    const int vmic = (lane < n_half) ? mics[lane * HC + wave] : 0;
+    struct Staged2 { float4 v0, v1; };
+    auto fetch = [&](int h) -> Staged2 {
+        const int mic = (h < kWave) ? __builtin_amdgcn_readlane(vmic, h) : mics[h * HC + wave];
+        Staged2 st;
+        st.v0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        st.v1 = st.v0;
+        if (4 * lane < N) {
+            st.v0 = *reinterpret_cast<const float4*>(sig0 + (size_t)mic * N + 4 * lane);
+            st.v1 = *reinterpret_cast<const float4*>(sig1 + (size_t)mic * N + 4 * lane);
+        }
+        return st;
+    };
+    auto stage = [&](int h, const Staged2& st, bool wipe) {
+        float* row0 = lds + (((h & 1) * HC) + wave) * G::kSlot;        // copy 0; copy 1 (shifted right by one sample) RS floats on
+        const float4 a0 = st.v0, a1 = st.v1;
+        float4* c0 = reinterpret_cast<float4*>(row0 + 2 * LEAD) + 2 * lane;
+        c0[0] = make_float4(a0.x, a1.x, a0.y, a1.y);
+        c0[1] = make_float4(a0.z, a1.z, a0.w, a1.w);
+        const float p0 = dpp_prev(a0.w), p1 = dpp_prev(a1.w);           // the previous lane's last sample (0 in lane 0: the prefix)
+        float4* c1 = reinterpret_cast<float4*>(row0 + RS + 2 * LEAD) + 2 * lane;
+        c1[0] = make_float4(p0, p1, a0.x, a1.x);
+        c1[1] = make_float4(a0.y, a1.y, a0.z, a1.z);
+        // the zero padding after the block (hybrid_convolve_and_sum.c:98-104), 8 samples = 4 quads per copy; copy 1 still holds the last sample
+        if (lane == kWave - 1) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4* t0 = reinterpret_cast<float4*>(row0 + 2 * (LEAD + 256));
+            t0[0] = z; t0[1] = z; t0[2] = z; t0[3] = z;
+            float4* t1 = reinterpret_cast<float4*>(row0 + RS + 2 * (LEAD + 256));
+            t1[0] = make_float4(a0.w, a1.w, 0.f, 0.f); t1[1] = z; t1[2] = z; t1[3] = z;
+        }
+        if (wipe) {
+            // the zero prefix (56 samples x 2 frames = 28 quads per copy): only the parked rows of the power pass overwrite it
+            static_assert((LEAD >> 1) * C <= kWave, "one lane per prefix quad");
+            constexpr int PQ = LEAD >> 1;
+            if (lane < PQ * C) reinterpret_cast<float4*>(row0 + (lane / PQ) * RS)[lane % PQ] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    Staged2 st = fetch(0);
+    const int lb = 32 * lane + (int)(unsigned)(size_t)((__attribute__((address_space(3))) char*)lds);   // a lane's window starts 4 samples x 2 frames on
+
+    for (int g0 = tile_begin; g0 < tile_end; g0 += kGroup) {
+        f32x2 acc[DW][4];                                       // (frame 0, frame 1) of output j of direction d
+#pragma unroll
+        for (int j = 0; j < DW; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[j][q] = f32x2{0.0f, 0.0f};
+
+        __syncthreads();   // the previous group's parked rows have been summed
+        stage(0, st, true);
+        st = fetch(1 % n_half);
+        __syncthreads();
+
+        const int dw0 = g0 + wave * DW;                         // wave-uniform
+        const bool busy = dw0 < tile_end;
+        const size_t grp = busy ? (size_t)(dw0 - a.dir_begin) / DW : 0;
+        for (int h = 0; h < n_half; ++h) {
+            if (h + 1 < n_half) {
+                stage(h + 1, st, h == 0);
+                if (h + 2 < n_half) st = fetch(h + 2);
+                else if (g0 + kGroup < tile_end) st = fetch(0);
+            }
+            if (busy) {
+                const int m0 = h * HC;
+                const int32_t* __restrict__ et = dig + (grp * M + m0) * DW;                       // LDS offsets, 8 per mic
+                const int32_t* __restrict__ nt = dig + a.digest_h_off + (grp * M + m0) * DW;      // packed guards, 8 per mic
+                // taps [D][M][8]: one row pointer per direction of the wave (directions past the end repeat the last one)
+                const unsigned long long* __restrict__ tp[DW];
+#pragma unroll
+                for (int j = 0; j < DW; ++j) tp[j] = reinterpret_cast<const unsigned long long*>(taps + ((size_t)min(dw0 + j, a.dir_end - 1) * M + m0) * 8);
+                struct Entries { int e[DW]; int n[DW]; };
+                struct Taps { unsigned long long h[4]; };
+                auto request = [&](Entries& t, int m) {
+#pragma unroll
+                    for (int j = 0; j < DW; ++j) { t.e[j] = et[m * DW + j]; t.n[j] = nt[m * DW + j]; }
+                };
+                auto request_taps = [&](Taps& t, auto jc, int m) {
+                    constexpr int j = decltype(jc)::value;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t.h[k] = tp[j][m * 4 + k];
+                };
+                Entries E[2];
+                Taps T[3];
+                f32x4 Q[6];
+                HybridMasks KM;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) Q[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                KM.m[0] = KM.m[1] = KM.m[2] = KM.m[3] = 0ull;
+                request(E[0], 0);
+                request_taps(T[0], std::integral_constant<int, 0>{}, 0);
+                request_taps(T[1], std::integral_constant<int, 1>{}, 0);
+                // steps (m, j) in order; the taps of step s = 8 m + j live in set s % 3 and are requested two steps ahead;
+                // 8 % 3 == 2, so the sets of mic m start at (2 m) % 3: three mics until the pattern repeats
+                auto mic = [&](int m, auto pc, auto rc) {
+                    constexpr int P = decltype(pc)::value, R = decltype(rc)::value;    // entry set, first taps set
+                    const Entries& cur = E[P];
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    hybrid_window_first(Q, KM, cur.e[0], cur.n[0], lb);
+                    request(E[P ^ 1], m + 1);                   // (past the half's last mic: inside the slack-padded table, dropped)
+                    auto stepj = [&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        // Scalar loads return out of order, so "this step's taps have landed" can only be a full wait -- placed
+                        // BEFORE the request for the step after next: what it covers was issued a whole step ago, and the new
+                        // request then has this step's arithmetic to land behind.
+                        if constexpr (j > 0) __builtin_amdgcn_s_waitcnt(0xC07F);
+                        if constexpr (j + 2 < DW) request_taps(T[(R + j + 2) % 3], std::integral_constant<int, j + 2>{}, m);
+                        else request_taps(T[(R + j + 2) % 3], std::integral_constant<int, j + 2 - DW>{}, m + 1);
+                        if constexpr (j > 0) hybrid_window(Q, KM, cur.e[j - 1], cur.e[j], cur.n[j], lb);
+                        hybrid_step(acc[j], Q, T[(R + j) % 3].h, KM);
+                    };
+                    stepj(std::integral_constant<int, 0>{}); stepj(std::integral_constant<int, 1>{});
+                    stepj(std::integral_constant<int, 2>{}); stepj(std::integral_constant<int, 3>{});
+                    stepj(std::integral_constant<int, 4>{}); stepj(std::integral_constant<int, 5>{});
+                    stepj(std::integral_constant<int, 6>{}); stepj(std::integral_constant<int, 7>{});
+                };
+                using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+                static_assert(HC == 16, "sixteen mics per half");
+#pragma unroll 1
+                for (int t = 0; t < 2; ++t) {                   // 6 mics per trip: entry sets alternate, taps sets repeat after 3 mics
+                    mic(0, I0{}, I0{}); mic(1, I1{}, I2{}); mic(2, I0{}, I1{}); mic(3, I1{}, I0{}); mic(4, I0{}, I2{}); mic(5, I1{}, I1{});
+                    et += 6 * DW; nt += 6 * DW;
+#pragma unroll
+                    for (int j = 0; j < DW; ++j) tp[j] += 6 * 4;
+                }
+                mic(0, I0{}, I0{}); mic(1, I1{}, I2{}); mic(2, I0{}, I1{}); mic(3, I1{}, I0{});
+                __builtin_amdgcn_s_waitcnt(0xC07F);             // the requests made past the half's end have landed (and are dropped)
+            }
+            __syncthreads();   // half h is free, half h + 1 is staged
+        }
+
+        // ---- k-ordered mean power (hybrid_convolve_and_sum.c:108-116), one frame at a time (see das_pair_kernel)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            if (f == 1) __syncthreads();        // frame 0's rows have been summed
+            auto park = [&](auto mul_c) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < DW; ++j) {
+                    float* row = lds + (wave * DW + j) * kPark;
+                    const float x0 = f == 0 ? acc[j][0].x : acc[j][0].y, x1 = f == 0 ? acc[j][1].x : acc[j][1].y;
+                    const float x2 = f == 0 ? acc[j][2].x : acc[j][2].y, x3 = f == 0 ? acc[j][3].x : acc[j][3].y;
+                    float o0, o1, o2, o3;
+                    if constexpr (decltype(mul_c)::value) {
+                        o0 = x0 * a.inv_n; o1 = x1 * a.inv_n; o2 = x2 * a.inv_n; o3 = x3 * a.inv_n;
+                    } else {
+                        float fm = (float)M;
+                        asm volatile("" : "+v"(fm));   // not speculatable: keeps this path behind its branch
+                        o0 = x0 / fm; o1 = x1 / fm; o2 = x2 / fm; o3 = x3 / fm;
+                    }
+                    reinterpret_cast<float4*>(row)[lane] = make_float4(o0 * o0, o1 * o1, o2 * o2, o3 * o3);
+                }
+            };
+            if (__builtin_expect(a.n_is_pow2, 1)) park(std::true_type{}); else park(std::false_type{});
+            __syncthreads();
+            const int g = wave * kWave + lane;            // parked row of this lane
+            const int d = g0 + g;
+            if (g < kGroup && d < tile_end && (f == 0 || two)) {
+                const float* row = lds + g * kPark;
+                const float4* row4 = reinterpret_cast<const float4*>(row);
+                float sum = 0.0f;
+                int k = 0;
+                for (; k + 32 <= N; k += 32) {
+                    float4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = row4[(k >> 2) + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { sum += v[u].x; sum += v[u].y; sum += v[u].z; sum += v[u].w; }
+                }
+                for (; k < N; ++k) sum += row[k];
+                (f == 0 ? img0 : img1)[d - a.image_origin] = sum / (float)N;
+            }
+        }
+    }
+}
+
+// ==================================================================================================
 // Long blocks: pad / lerp at 256 < N <= 1024 (2 or 4 segments of 256 samples per row; BASELINE config 5: 256 mics x 1024).
 //
 // The sweep of das_copies_kernel with the chunk handling of das_pair_kernel and a conflict-free lane mapping:
@@ -2191,6 +2494,21 @@ hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, in
                     return hipGetLastError();
                 }
             }
+            if constexpr (ALGO == ALGO_HYBRID) {
+                if (plan.nf == 2) {                             // das_hybrid_pair_kernel
+                    using HG = copies::HybridGeo;
+                    if (L.tab.digest == nullptr || plan.waves != copies::kWaves || plan.mic_chunk != HG::kMc || plan.row_stride != HG::kRs ||
+                        plan.lead != HG::kLead || (L.n_mics % 16) != 0 || L.n_taps != 8)
+                        return hipErrorInvalidValue;
+                    auto kernel = copies::das_hybrid_pair_kernel;
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
+                    if (e != hipSuccess) return e;
+                    const dim3 pair_grid((unsigned)plan.n_tiles * (unsigned)((frames + 1) / 2));
+                    hipLaunchKernelGGL(kernel, pair_grid, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole,
+                                       reinterpret_cast<const float*>(L.tab.digest), L.tab.taps, a);
+                    return hipGetLastError();
+                }
+            }
             if constexpr (!kFir && (NSEG == 2 || NSEG == 4)) {
                 if (plan.long_rows) {                           // das_long_kernel
                     using LG = copies::LongGeo<ALGO, NSEG>;
@@ -2316,7 +2634,7 @@ KArgs make_args(const DasLaunch& L, const DasPlan& plan)
     a.n_frames = L.frames;
     a.wg_frames = plan.nf == 2 ? (L.frames + 1) / 2 : L.frames;
     a.frame_inner = plan.frame_inner;
-    a.digest_h_off = (plan.layout == 2 && L.algo == ALGO_LERP) ? grouped_entries_for_args(L, plan) : 0;
+    a.digest_h_off = (plan.layout == 2 && (L.algo == ALGO_LERP || (L.algo == ALGO_HYBRID && plan.nf == 2))) ? grouped_entries_for_args(L, plan) : 0;
     return a;
 }
 
@@ -2406,6 +2724,15 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
             p.nf = 2;
             mc = 16;
         }
+        // The hybrid beamformer's two-frame sweep (das_hybrid_pair_kernel) under the same conditions.  (debug bit 13: A/B switch)
+        if (L.algo == ALGO_HYBRID && nseg == 1 && L.n_taps == 8 && waves == copies::kWaves && p.lead == fixed_lead && (L.n_mics % 16) == 0 &&
+            (L.n_samples % 4) == 0 && L.frames >= 2 && !(L.debug & 8192)) {
+            p.nf = 2;
+            mc = copies::HybridGeo::kMc;                        // 32 mic slots: two frames interleaved per row, two shifted copies
+            p.copies = copies::HybridGeo::kC;
+            p.row_stride = copies::HybridGeo::kRs;
+        }
+        const bool hybrid_pair = L.algo == ALGO_HYBRID && p.nf == 2;
         // Long rows (2 / 4 segments): das_long_kernel where its LDS image -- two halves of 16 / nseg mics -- fits and the mic count is
         // a whole number of halves.  (debug bit 12: A/B switch back to das_copies_kernel)
         p.long_rows = 0;
@@ -2419,7 +2746,7 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
         p.mic_chunk = mc; p.n_chunks = (L.n_mics + mc - 1) / mc;
         p.waves = waves; p.dpw = dw; p.srow = nseg * 256 + 4;
         p.scratch_off = 0;
-        const size_t buf = slot_bytes * (size_t)mc * (size_t)p.nf;
+        const size_t buf = hybrid_pair ? (size_t)mc * copies::HybridGeo::kSlot * sizeof(float) : slot_bytes * (size_t)mc * (size_t)p.nf;
         const size_t wave_rows = (size_t)dw * p.srow * sizeof(float);          // the parked rows of one wave
         p.lds_bytes = buf > 2 * wave_rows ? buf : 2 * wave_rows;
         if (p.long_rows && p.lds_bytes < 8 * wave_rows) p.lds_bytes = 8 * wave_rows;             // eight waves park together (two rounds)
@@ -2493,7 +2820,7 @@ size_t digest_elements(const DasLaunch& L, const DasPlan& plan)
     const size_t direct = (size_t)L.n_dirs * (size_t)L.n_mics;                 // the [D][M] layout of the DIRECT variant
     if (L.algo == ALGO_PAD) return std::max((size_t)grouped_entries(L, plan), direct);
     if (L.algo == ALGO_LERP) return std::max((size_t)(2 * grouped_entries(L, plan)), direct);    // offsets, then the lerp weights in the same order
-    if (L.algo == ALGO_HYBRID) return (size_t)L.n_dirs * (size_t)L.n_mics;
+    if (L.algo == ALGO_HYBRID) return std::max((size_t)L.n_dirs * (size_t)L.n_mics, plan.nf == 2 ? (size_t)(2 * grouped_entries(L, plan)) : (size_t)0);   // pair kernel: offsets, then the packed guards
     return 0;
 }
 
@@ -2502,15 +2829,16 @@ hipError_t launch_digest(const DasLaunch& L, const DasPlan& plan, int32_t* d_dig
     // what the kernel looks back by beyond the whole-sample delay: lerp reads s[k - p - 1], hybrid starts its window at
     // s[k - p - 1 - T/2] (T = 8)
     // (`arrays`: rows of one staged mic in units of its shifted copies -- samples, lerp's differences, and both frames of the pair kernel)
-    const int arrays = ((L.algo == ALGO_LERP) ? 2 : 1) * (plan.nf == 2 ? 2 : 1), bias = (L.algo == ALGO_LERP) ? 1 : (L.algo == ALGO_HYBRID) ? 5 : 0;
-    if (L.algo == ALGO_HYBRID || direct) {
+    // (the hybrid pair kernel interleaves its two frames inside a row: one array per mic)
+    const int arrays = ((L.algo == ALGO_LERP) ? 2 : 1) * ((plan.nf == 2 && L.algo != ALGO_HYBRID) ? 2 : 1), bias = (L.algo == ALGO_LERP) ? 1 : (L.algo == ALGO_HYBRID) ? 5 : 0;
+    if ((L.algo == ALGO_HYBRID && plan.nf != 2) || direct) {
         hipLaunchKernelGGL(digest_kernel, dim3(1024), dim3(256), 0, stream, L.tab.whole, d_digest, (long long)L.n_dirs * L.n_mics, L.n_mics, plan.mic_chunk,
                            arrays, plan.row_stride, plan.lead, bias, plan.copies);
     } else {
         const long long entries = grouped_entries(L, plan);
         hipLaunchKernelGGL(digest_grouped_kernel, dim3(1024), dim3(256), 0, stream, L.tab.whole, L.algo == ALGO_LERP ? L.tab.frac : nullptr, d_digest,
                            entries, entries, L.n_mics, plan.dpw, L.dir_begin, L.dir_end, plan.mic_chunk, arrays, plan.row_stride, plan.lead, bias,
-                           plan.copies, d_reload_count);
+                           plan.copies, d_reload_count, L.algo == ALGO_HYBRID ? 1 : 0);
     }
     return hipGetLastError();
 }
