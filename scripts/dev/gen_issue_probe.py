@@ -42,6 +42,10 @@ CONFIGS = [
     dict(name="alt16_f", waves=16, F=2, DW=8, read="b64", pre=True, check=True, lerp=True, tab=True, alt=True),
     dict(name="pad_pre16_c", waves=16, F=2, DW=8, read="b64c", pre=True, check=True, lerp=False, tab=True),
     dict(name="pad_alt16_c", waves=16, F=2, DW=8, read="b64c", pre=True, check=True, lerp=False, tab=True, alt=True),
+    # frames interleaved in LDS: 4 ds_read_b128 per (re)load instead of 8 ds_read_b64
+    dict(name="cur16_b128", waves=16, F=2, DW=8, read="b128", pre=False, check=True, lerp=True, tab=True),
+    dict(name="pre16_b128", waves=16, F=2, DW=8, read="b128", pre=True, check=True, lerp=True, tab=True),
+    dict(name="pad_cur16_b128", waves=16, F=2, DW=8, read="b128", pre=False, check=True, lerp=False, tab=True),
     # pad flavours
     dict(name="pad_pure16", waves=16, F=2, DW=8, read="none", pre=False, check=False, lerp=False, tab=False),
     dict(name="pad_cur16", waves=16, F=2, DW=8, read="b64c", pre=False, check=True, lerp=False, tab=True),
@@ -105,12 +109,22 @@ def gen_kernel(c):
             L.append("v_add_u32 v1, %s, v0" % ev)
 
     def reads(s):
+        if c["read"] == "b128":
+            # frames interleaved sample by sample: per array two 16-byte reads (sample pairs 2l, 2l+1 and 128+2l, 128+2l+1 of both frames)
+            assert F == 2
+            for a in range(A):
+                for hh in range(2):
+                    b = q0 + s * nq + (a * 2 + hh) * 4
+                    L.append("ds_read_b128 v[%d:%d], v1 offset:%d" % (b, b + 3, a * 2 * rowb + hh * 1024))
+            return
         for f in range(F):
             for a in range(A):
                 r = f * A + a
                 if c["read"] == "r2":
                     off = (r % 2) * rowb
                     L.append("ds_read2_b64 %s, v%d offset0:%d offset1:%d" % (quad4(s, f, a), 1 + r // 2, off // 8, off // 8 + 64))
+                elif c["read"] == "b128":
+                    pass
                 elif c["read"] in ("b64", "b64c"):
                     off = r * rowb
                     second = 512 if c["read"] == "b64" else 8
@@ -195,7 +209,7 @@ def gen_kernel(c):
     # prologue: zero everything, lane base, first table rows
     L.append("v_mbcnt_lo_u32_b32 v0, -1, 0")
     L.append("v_mbcnt_hi_u32_b32 v0, -1, v0")
-    L.append("v_lshlrev_b32 v0, %d, v0" % (4 if c["read"] == "b64c" else 3))
+    L.append("v_lshlrev_b32 v0, %d, v0" % (4 if c["read"] in ("b64c", "b128") else 3))
     for r in range(acc0, top):
         L.append("v_mov_b32 v%d, 0" % r)
     L.append("s_mov_b64 s[2:3], %[tab]")
@@ -257,9 +271,9 @@ int main(int argc, char** argv)
     auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (double)(rng >> 11) / 9007199254740992.0; };
     long long changes = 0;
     for (int m = 0; m < mics + 8; ++m) {
-        int ecur = 8 * (int)(rnd() * 8);
+        int ecur = 16 * (int)(rnd() * 8);
         for (int j = 0; j < 8; ++j) {
-            if (j > 0 && rnd() < p_change) { ecur = (ecur + 8) % 128; ++changes; }
+            if (j > 0 && rnd() < p_change) { ecur = (ecur + 16) % 256; ++changes; }
             tab[16 * m + j] = ecur;
         }
         for (int j = 8; j < 16; ++j) { float h = 0.25f + 0.001f * j; memcpy(&tab[16 * m + j], &h, 4); }

@@ -1796,14 +1796,21 @@ __global__ void __launch_bounds__(1024, 4) das_pair_kernel(BF_TABLE_PARAMS, KArg
         BF_STAMP(3);
 
         for (int h = 0; h < n_half; ++h) {
-            if (h + 1 < n_half) {
-                stage(h + 1, st, h == 0);                       // into the half whose sweeps ended before the last barrier
-                // request what is staged an iteration from now: half h + 2, or the next group's first half (the same rows)
-                if (h + 2 < n_half) st = fetch(h + 2);
-                else if (g0 + kGroup < tile_end) st = fetch(0);
-                BF_STAMP(2);
-            }
+            // Staging of the next half, somewhere inside this half's sweep.  The four waves of a SIMD (wave, wave + 4, + 8, + 12) do
+            // it at four different points -- before the first mic, after the third, the sixth, the seventh -- so that a SIMD never
+            // has all its waves queueing at the LDS store path (13 cycles per ds_write_b128 and wave) at once.
+            const int stage_slot = (a.debug & 16384) ? 0 : (wave >> 2);   // (debug bit 14: all at the start, A/B)
+            auto stage_next = [&]() {
+                if (h + 1 < n_half) {
+                    stage(h + 1, st, h == 0);                   // into the half whose sweeps ended before the last barrier
+                    // request what is staged an iteration from now: half h + 2, or the next group's first half (the same rows)
+                    if (h + 2 < n_half) st = fetch(h + 2);
+                    else if (g0 + kGroup < tile_end) st = fetch(0);
+                    BF_STAMP(2);
+                }
+            };
             const int dw0 = g0 + wave * DW;                     // wave-uniform
+            if (stage_slot == 0 || dw0 >= tile_end) stage_next();
             if (dw0 < tile_end) {
                 const size_t grp = (size_t)(dw0 - a.dir_begin) / DW;
                 const int32_t* __restrict__ et = dig + (grp * M + (size_t)h * HC) * DW;
@@ -1839,8 +1846,10 @@ __global__ void __launch_bounds__(1024, 4) das_pair_kernel(BF_TABLE_PARAMS, KArg
                 for (int t = 0; t < 2; ++t) {
                     mic(0, I0{}); mic(1, I1{}); mic(2, I2{});
                     et += 3 * DW; ht += 3 * DW;
+                    if (stage_slot == t + 1) stage_next();
                 }
                 mic(0, I0{});
+                if (stage_slot == 3) stage_next();
                 mic(1, I1{});
             }
             BF_STAMP(0);       // sweep -> waiting for the others
