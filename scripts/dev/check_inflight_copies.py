@@ -19,7 +19,7 @@ usage: python scripts/dev/check_inflight_copies.py [file.s]     (without a file:
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-KERNEL_RE = re.compile(r"^(_ZN2bf\S*(das_copies_kernel|das_pair_kernel|das_long_kernel|das_hybrid_pair_kernel)\S*):")
+KERNEL_RE = re.compile(r"^(_ZN2bf\S*(das_copies_kernel|das_pair_kernel|das_pair2_kernel|das_long_kernel|das_hybrid_pair_kernel)\S*):")
 MAX_QUEUE = 24          # lgkmcnt is a 4-bit counter; older entries than this cannot be told apart by any wait
 
 
@@ -173,6 +173,28 @@ def scan_kernel(insts, labels):
     return sorted(bad.items())
 
 
+def hardwired_gaps(path):
+    """das_pair2_kernel keeps a mic's quads in hard-wired registers (v96..v120, named as clobbers) from its statement S1 (reads, step 0)
+    to its statement S2 (steps 1..7); the compiler is free to use those registers in between.  -> [(line, instruction)] for every
+    instruction between a ';BF_S1_END' and the next ';BF_S2_BEGIN' that names one of v96..v120 (only table requests belong there)."""
+    bad, inside, pairs = [], False, 0
+    for lineno, line in enumerate(open(path), 1):
+        if "BF_S1_END" in line:
+            inside = True
+            continue
+        if "BF_S2_BEGIN" in line:
+            inside, pairs = False, pairs + 1
+            continue
+        if not inside:
+            continue
+        l = line.split(";")[0].strip()
+        if not l or l.startswith(".") or l.endswith(":"):
+            continue
+        if all_vregs(l) & set(range(96, 121)):           # (other vector work, e.g. a compare on loop state, is harmless)
+            bad.append((lineno, l))
+    return pairs, bad
+
+
 def metadata(path):
     """{mangled kernel name: dict(spill=, scratch=, vgprs=)} from the .amdgpu_metadata block of the assembly."""
     txt = open(path).read()
@@ -205,8 +227,13 @@ if __name__ == "__main__":
     kernels, bad = scan(path)
     for b in bad[:20]:
         print("REGISTER WITH A READ IN FLIGHT TOUCHED: %s line %d: %s" % b)
+    pairs, gaps = hardwired_gaps(path)
+    for g in gaps[:10]:
+        print("VECTOR INSTRUCTION BETWEEN S1 AND S2 OF A HARD-WIRED MIC: line %d: %s" % g)
+    print("%d S1/S2 gaps checked" % pairs)
+    bad = bad + [("gap", g[0], g[1]) for g in gaps]
     md = metadata(path)
-    names = [n for n in md if "das_copies_kernel" in n or "das_pair_kernel" in n or "das_long_kernel" in n or "das_hybrid_pair_kernel" in n]
+    names = [n for n in md if any(k in n for k in ("das_copies_kernel", "das_pair_kernel", "das_pair2_kernel", "das_long_kernel", "das_hybrid_pair_kernel"))]
     for n, d in zip(names, demangle(names)):
         if md[n]["spill"] or md[n]["scratch"]:
             print("SPILLS: %-60s vgprs %3d spill %d scratch %d" % (d, md[n]["vgprs"], md[n]["spill"], md[n]["scratch"]))

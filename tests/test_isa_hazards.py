@@ -60,7 +60,7 @@ def test_scanner_finds_what_it_should(chk, tmp_path, body, n_bad):
 
 def test_no_register_with_a_read_in_flight_is_touched(chk, asm):
     kernels, bad = chk.scan(asm)
-    assert kernels >= 39
+    assert kernels >= 41
     assert not bad, bad[:5]
 
 
@@ -70,7 +70,7 @@ def test_every_launchable_instantiation_is_scanned_and_none_that_pipelines_reads
     flavours.  The instantiations that keep LDS reads in flight across asm statements (pair kernel; one-segment sweep) must not
     use scratch: a spilled register with a read in flight is reloaded before the data lands."""
     md = chk.metadata(asm)
-    names = [n for n in md if "das_copies_kernel" in n or "das_pair_kernel" in n or "das_long_kernel" in n or "das_hybrid_pair_kernel" in n]
+    names = [n for n in md if any(k in n for k in ("das_copies_kernel", "das_pair_kernel", "das_pair2_kernel", "das_long_kernel", "das_hybrid_pair_kernel"))]
     short = dict(zip(chk.demangle(names), names))
     want = ["bf::copies::das_pair_kernel<%d>" % a for a in (0, 1)]
     for a in (0, 1):
@@ -78,7 +78,7 @@ def test_every_launchable_instantiation_is_scanned_and_none_that_pipelines_reads
         want += ["bf::copies::das_copies_kernel<%d, %d, %d, 16, %s>" % (a, seg, rs, d) for seg, fixed in ((2, 576), (4, 1088)) for rs in (fixed, 0) for d in ("false", "true")]
     want += ["bf::copies::das_copies_kernel<%d, 1, %d, 16, false>" % (a, rs) for a in (2, 3, 4) for rs in (320, 0)]
     want += ["bf::copies::das_long_kernel<%d, %d, %d>" % (a, seg, rs) for a in (0, 1) for seg, fixed in ((2, 576), (4, 1088)) for rs in (fixed, 0)]
-    want += ["bf::copies::das_hybrid_pair_kernel"]
+    want += ["bf::copies::das_hybrid_pair_kernel", "bf::copies::das_pair2_kernel<0>", "bf::copies::das_pair2_kernel<1>"]
     missing = [w for w in want if w not in short]
     assert not missing, missing
     kernels, _ = chk.scan(asm)
@@ -90,3 +90,12 @@ def test_every_launchable_instantiation_is_scanned_and_none_that_pipelines_reads
         m = md[short[w]]
         assert m["spill"] == 0 and m["scratch"] == 0, (w, m)
         assert m["vgprs"] <= 128                        # 16 waves per CU
+
+
+def test_hardwired_quads_survive_between_the_two_statements_of_a_mic(chk, asm):
+    """das_pair2_kernel reads a mic's quads into v96..v111 in its statement S1 and consumes them in S2; both name those registers
+    as clobbers, so the compiler may use them in between -- where only the scalar table requests belong.  No instruction in any
+    S1 -> S2 gap of the generated code may name one of those registers."""
+    pairs, bad = chk.hardwired_gaps(asm)
+    assert pairs >= 2 * 5          # pad and lerp, five mic bodies each (three in the trip loop, two after it)
+    assert not bad, bad[:5]

@@ -62,6 +62,7 @@ struct DasPlan {
     int layout;      // 0 strided, 1 quad + DPP, 2 shifted copies (pad / lerp, N <= 256)
     int dpw;         // directions a wave carries across mic chunks
     int nf;          // frames a workgroup carries (2: das_pair_kernel -- pad / lerp at N <= 256 with the fixed row stride, a multiple of 16 mics and two or more frames)
+    int interleaved; // 1: two-frame kernels whose LDS rows hold both frames interleaved sample by sample (das_pair2_kernel, das_hybrid_pair_kernel)
     int long_rows;   // 1: das_long_kernel (pad / lerp at 256 < N <= 1024: LDS image in two halves, conflict-free lane mapping)
     int frame_inner; // workgroup id -> (tile, frame): 1 = an XCD runs all frames of a tile back to back (tables beyond the L2s)
     int copies;      // layout 2: shifted copies per staged array (2: the sweep of pad / lerp, 4: FIR flavours and the DIRECT variant)

@@ -672,7 +672,7 @@ __global__ void __launch_bounds__(256) digest_kernel(const int32_t* __restrict__
 __global__ void __launch_bounds__(256) digest_grouped_kernel(const int32_t* __restrict__ whole, const float* __restrict__ frac, int32_t* __restrict__ digest,
                                                              long long entries, long long h_off, int n_mics, int gdirs, int dir_begin, int dir_end,
                                                              int mic_chunk, int arrays, int row_stride, int lead, int bias, int ncopies,
-                                                             unsigned long long* __restrict__ reload_count, int pack_guards)
+                                                             unsigned long long* __restrict__ reload_count, int pack_guards, int scale)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < entries; i += (long long)gridDim.x * blockDim.x) {
         const int j = (int)(i % gdirs);
@@ -683,8 +683,8 @@ __global__ void __launch_bounds__(256) digest_grouped_kernel(const int32_t* __re
         if (d > dir_end - 1) d = dir_end - 1;
         const int m = mic % mic_chunk;
         const int pd = whole[d * n_mics + mic] + bias;
-        // (pack_guards = the hybrid pair kernel: rows hold two frames interleaved, a sample is two floats wide)
-        digest[i] = ((m * arrays * ncopies + (pd & (ncopies - 1))) * row_stride + (pack_guards ? 2 : 1) * (lead - (pd & ~(ncopies - 1)))) * 4;
+        // (scale = 2: rows hold two frames interleaved sample by sample, a sample is two floats wide)
+        digest[i] = ((m * arrays * ncopies + (pd & (ncopies - 1))) * row_stride + scale * (lead - (pd & ~(ncopies - 1)))) * 4;
         if (frac != nullptr) reinterpret_cast<float*>(digest)[h_off + i] = frac[d * n_mics + mic];
         if (pack_guards) {
             // hybrid: output j of a lane (sample 4 lane + j) is live for 4 lane + j > p, i.e. from lane n_j = (p + 4 - j) >> 2 on;
@@ -1796,21 +1796,14 @@ __global__ void __launch_bounds__(1024, 4) das_pair_kernel(BF_TABLE_PARAMS, KArg
         BF_STAMP(3);
 
         for (int h = 0; h < n_half; ++h) {
-            // Staging of the next half, somewhere inside this half's sweep.  The four waves of a SIMD (wave, wave + 4, + 8, + 12) do
-            // it at four different points -- before the first mic, after the third, the sixth, the seventh -- so that a SIMD never
-            // has all its waves queueing at the LDS store path (13 cycles per ds_write_b128 and wave) at once.
-            const int stage_slot = (a.debug & 16384) ? 0 : (wave >> 2);   // (debug bit 14: all at the start, A/B)
-            auto stage_next = [&]() {
-                if (h + 1 < n_half) {
-                    stage(h + 1, st, h == 0);                   // into the half whose sweeps ended before the last barrier
-                    // request what is staged an iteration from now: half h + 2, or the next group's first half (the same rows)
-                    if (h + 2 < n_half) st = fetch(h + 2);
-                    else if (g0 + kGroup < tile_end) st = fetch(0);
-                    BF_STAMP(2);
-                }
-            };
+            if (h + 1 < n_half) {
+                stage(h + 1, st, h == 0);                       // into the half whose sweeps ended before the last barrier
+                // request what is staged an iteration from now: half h + 2, or the next group's first half (the same rows)
+                if (h + 2 < n_half) st = fetch(h + 2);
+                else if (g0 + kGroup < tile_end) st = fetch(0);
+                BF_STAMP(2);
+            }
             const int dw0 = g0 + wave * DW;                     // wave-uniform
-            if (stage_slot == 0 || dw0 >= tile_end) stage_next();
             if (dw0 < tile_end) {
                 const size_t grp = (size_t)(dw0 - a.dir_begin) / DW;
                 const int32_t* __restrict__ et = dig + (grp * M + (size_t)h * HC) * DW;
@@ -1846,10 +1839,8 @@ __global__ void __launch_bounds__(1024, 4) das_pair_kernel(BF_TABLE_PARAMS, KArg
                 for (int t = 0; t < 2; ++t) {
                     mic(0, I0{}); mic(1, I1{}); mic(2, I2{});
                     et += 3 * DW; ht += 3 * DW;
-                    if (stage_slot == t + 1) stage_next();
                 }
                 mic(0, I0{});
-                if (stage_slot == 3) stage_next();
                 mic(1, I1{});
             }
             BF_STAMP(0);       // sweep -> waiting for the others
@@ -1915,6 +1906,304 @@ __global__ void __launch_bounds__(1024, 4) das_pair_kernel(BF_TABLE_PARAMS, KArg
 #undef BF_P_ADDR
 #undef BF_P_CHECK
 #undef BF_P_STUB
+
+// ==================================================================================================
+// Two frames per workgroup, frames INTERLEAVED sample by sample in the LDS rows (pad / lerp, N <= 256; das_pair_kernel's successor).
+//
+// Every instruction costs a SIMD a quad-cycle, so what is left to gain on the sweep is instruction count.  With the
+// row of a mic holding (f0 s0, f1 s0, f0 s1, f1 s1, ..):
+//   * one ds_read_b128 brings two samples of BOTH frames: a (re)load is 2 (pad) / 4 (lerp) LDS instructions instead of 4 / 8, and
+//     with lane l owning the sample pairs (2l, 2l+1) and (128+2l, 128+2l+1) every read covers 1 KiB of contiguous LDS (no bank
+//     conflicts; the 16-byte lane stride of ds_read_b64 pairs was a two-way conflict on every read);
+//   * a register pair is (frame 0, frame 1) of one sample, so the packed operations are the same 4 (pad) / 8 (lerp) per
+//     direction step, the lerp weight still one scalar operand for both lanes;
+//   * the quads live in HARD-WIRED registers v[96:111] (+ products v[112:119], address v120), named as clobbers: 16-byte reads
+//     need 4-register tuples whose halves the packed operations address, which inline-asm operands cannot express.  A mic is
+//     two statements -- S1: address, reads, wait, step 0;  S2: steps 1..7 with their tests and out-of-line re-reads -- and the
+//     quads must survive from S1 to S2 across the table requests the compiler places between them (scalar instructions only;
+//     tests/test_isa_hazards.py checks that nothing between the two markers touches a vector register).
+// Halves of 8 mics staged under the sweep, power pass, digest: as das_pair_kernel (digest offsets scaled for the 2-float samples).
+template <int ALGO>
+struct Pair2Geo {
+    static constexpr bool kLerp = ALGO == ALGO_LERP;
+    static constexpr int kA = kLerp ? 2 : 1, kC = 2, kLead = Geo<1>::kLead, kRs = 2 * Geo<1>::kRs, kMc = 16, kHalf = 8;
+    static constexpr int kSlot = kA * kC * kRs;          // floats per staged mic (both frames)
+    static constexpr int kDoff = kC * kRs * 4;           // bytes from a sample quad to its difference quad
+};
+
+#define BF_I_ACC(n, j) [a##n##0] "+v"(acc[j][0]), [a##n##1] "+v"(acc[j][1]), [a##n##2] "+v"(acc[j][2]), [a##n##3] "+v"(acc[j][3])
+#define BF_I_READ_PAD "ds_read_b128 v[96:99], v120\n\tds_read_b128 v[100:103], v120 offset:1024\n\ts_waitcnt lgkmcnt(0)\n\t"
+#define BF_I_READ_LERP                                                                              \
+    "ds_read_b128 v[96:99], v120\n\tds_read_b128 v[100:103], v120 offset:1024\n\t"                   \
+    "ds_read_b128 v[104:107], v120 offset:%[g0]\n\tds_read_b128 v[108:111], v120 offset:%[g1]\n\ts_waitcnt lgkmcnt(0)\n\t"
+#define BF_I_PAD_STEP(n)                                                                            \
+    "v_pk_add_f32 %[a" #n "0], %[a" #n "0], v[96:97]\n\tv_pk_add_f32 %[a" #n "1], %[a" #n "1], v[98:99]\n\t" \
+    "v_pk_add_f32 %[a" #n "2], %[a" #n "2], v[100:101]\n\tv_pk_add_f32 %[a" #n "3], %[a" #n "3], v[102:103]\n\t"
+#define BF_I_LERP_STEP(n, h, mods)                                                                  \
+    "v_pk_fma_f32 v[112:113], %[" #h "], v[104:105], v[96:97] " mods "\n\tv_pk_fma_f32 v[114:115], %[" #h "], v[106:107], v[98:99] " mods "\n\t" \
+    "v_pk_fma_f32 v[116:117], %[" #h "], v[108:109], v[100:101] " mods "\n\tv_pk_fma_f32 v[118:119], %[" #h "], v[110:111], v[102:103] " mods "\n\t" \
+    "v_pk_add_f32 %[a" #n "0], %[a" #n "0], v[112:113]\n\tv_pk_add_f32 %[a" #n "1], %[a" #n "1], v[114:115]\n\t" \
+    "v_pk_add_f32 %[a" #n "2], %[a" #n "2], v[116:117]\n\tv_pk_add_f32 %[a" #n "3], %[a" #n "3], v[118:119]\n\t"
+#define BF_I_EVEN "op_sel_hi:[0,1,1]"
+#define BF_I_ODD "op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+#define BF_I_CHECK(n, ep, ec) "s_cmp_lg_u32 %[" #ec "], %[" #ep "]\n\ts_cbranch_scc1 .Lr" #n "_%=\n.Lb" #n "_%=:\n\t"
+#define BF_I_STUB(n, ec, READ) ".Lr" #n "_%=:\n\tv_add_u32 v120, %[" #ec "], %[lb]\n\t" READ "s_branch .Lb" #n "_%=\n"
+#define BF_I_CLOB "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", \
+                  "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120"
+
+// S1: a mic's first quads, read in place, and direction step 0
+template <int ALGO>
+__device__ __forceinline__ void pair2_first(f32x2 (&acc)[8][4], int e0, unsigned long long h01, int lbase)
+{
+    using G = Pair2Geo<ALGO>;
+    if constexpr (ALGO == ALGO_PAD) {
+        // pad_and_sum.c:41-47   out[k] += s[k - p]
+        asm volatile("v_add_u32 v120, %[e0], %[lb]\n\t" BF_I_READ_PAD BF_I_PAD_STEP(0) ";BF_S1_END"
+                     : BF_I_ACC(0, 0) : [e0] "s"(e0), [lb] "v"(lbase) : BF_I_CLOB);
+    } else {
+        // lerp_and_sum.c:50-56  out[k] += s[i] + h * (s[i+1] - s[i]),  i = k - p - 1   (gcc contracts it into one fma)
+        asm volatile("v_add_u32 v120, %[e0], %[lb]\n\t" BF_I_READ_LERP BF_I_LERP_STEP(0, h01, BF_I_EVEN) ";BF_S1_END"
+                     : BF_I_ACC(0, 0) : [e0] "s"(e0), [h01] "s"(h01), [lb] "v"(lbase), [g0] "n"(G::kDoff), [g1] "n"(G::kDoff + 1024) : BF_I_CLOB);
+    }
+}
+// S2: direction steps 1..7, each behind the test of its LDS offset against the previous step's
+template <int ALGO>
+__device__ __forceinline__ void pair2_rest(f32x2 (&acc)[8][4], const int (&e)[8], const unsigned long long (&hp)[4], int lbase)
+{
+    using G = Pair2Geo<ALGO>;
+#define BF_I_S2_ACCS BF_I_ACC(1, 1), BF_I_ACC(2, 2), BF_I_ACC(3, 3), BF_I_ACC(4, 4), BF_I_ACC(5, 5), BF_I_ACC(6, 6), BF_I_ACC(7, 7)
+#define BF_I_S2_E [e0] "s"(e[0]), [e1] "s"(e[1]), [e2] "s"(e[2]), [e3] "s"(e[3]), [e4] "s"(e[4]), [e5] "s"(e[5]), [e6] "s"(e[6]), [e7] "s"(e[7]), [lb] "v"(lbase)
+    if constexpr (ALGO == ALGO_PAD) {
+        asm volatile(";BF_S2_BEGIN\n\t"
+                     BF_I_CHECK(1, e0, e1) BF_I_PAD_STEP(1) BF_I_CHECK(2, e1, e2) BF_I_PAD_STEP(2) BF_I_CHECK(3, e2, e3) BF_I_PAD_STEP(3)
+                     BF_I_CHECK(4, e3, e4) BF_I_PAD_STEP(4) BF_I_CHECK(5, e4, e5) BF_I_PAD_STEP(5) BF_I_CHECK(6, e5, e6) BF_I_PAD_STEP(6)
+                     BF_I_CHECK(7, e6, e7) BF_I_PAD_STEP(7)
+                     ".subsection 1\n" BF_I_STUB(1, e1, BF_I_READ_PAD) BF_I_STUB(2, e2, BF_I_READ_PAD) BF_I_STUB(3, e3, BF_I_READ_PAD)
+                     BF_I_STUB(4, e4, BF_I_READ_PAD) BF_I_STUB(5, e5, BF_I_READ_PAD) BF_I_STUB(6, e6, BF_I_READ_PAD) BF_I_STUB(7, e7, BF_I_READ_PAD)
+                     "\t.subsection 0"
+                     : BF_I_S2_ACCS : BF_I_S2_E : "scc", BF_I_CLOB);
+    } else {
+        asm volatile(";BF_S2_BEGIN\n\t"
+                     BF_I_CHECK(1, e0, e1) BF_I_LERP_STEP(1, h01, BF_I_ODD) BF_I_CHECK(2, e1, e2) BF_I_LERP_STEP(2, h23, BF_I_EVEN)
+                     BF_I_CHECK(3, e2, e3) BF_I_LERP_STEP(3, h23, BF_I_ODD) BF_I_CHECK(4, e3, e4) BF_I_LERP_STEP(4, h45, BF_I_EVEN)
+                     BF_I_CHECK(5, e4, e5) BF_I_LERP_STEP(5, h45, BF_I_ODD) BF_I_CHECK(6, e5, e6) BF_I_LERP_STEP(6, h67, BF_I_EVEN)
+                     BF_I_CHECK(7, e6, e7) BF_I_LERP_STEP(7, h67, BF_I_ODD)
+                     ".subsection 1\n" BF_I_STUB(1, e1, BF_I_READ_LERP) BF_I_STUB(2, e2, BF_I_READ_LERP) BF_I_STUB(3, e3, BF_I_READ_LERP)
+                     BF_I_STUB(4, e4, BF_I_READ_LERP) BF_I_STUB(5, e5, BF_I_READ_LERP) BF_I_STUB(6, e6, BF_I_READ_LERP) BF_I_STUB(7, e7, BF_I_READ_LERP)
+                     "\t.subsection 0"
+                     : BF_I_S2_ACCS
+                     : BF_I_S2_E, [h01] "s"(hp[0]), [h23] "s"(hp[1]), [h45] "s"(hp[2]), [h67] "s"(hp[3]), [g0] "n"(G::kDoff), [g1] "n"(G::kDoff + 1024)
+                     : "scc", BF_I_CLOB);
+    }
+#undef BF_I_S2_ACCS
+#undef BF_I_S2_E
+}
+#undef BF_I_ACC
+#undef BF_I_READ_PAD
+#undef BF_I_READ_LERP
+#undef BF_I_PAD_STEP
+#undef BF_I_LERP_STEP
+#undef BF_I_EVEN
+#undef BF_I_ODD
+#undef BF_I_CHECK
+#undef BF_I_STUB
+#undef BF_I_CLOB
+
+template <int ALGO>
+__global__ void __launch_bounds__(1024, 4) das_pair2_kernel(BF_TABLE_PARAMS, KArgs a)
+{
+    using G = Pair2Geo<ALGO>;
+    constexpr bool kLerp = G::kLerp;
+    constexpr int A = G::kA, C = G::kC, RS = G::kRs, LEAD = G::kLead, HC = G::kHalf, W = 16, DW = 8, kGroup = DW * W, kPark = Geo<1>::kPark;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int tile, fpair;
+    tile_and_frame(a, &tile, &fpair);
+    const int f0 = 2 * fpair;
+    const bool two = f0 + 1 < a.n_frames;                      // an odd frame count: the last workgroup row computes its frame twice
+    const int f1 = two ? f0 + 1 : f0;
+    const int tile_begin = a.dir_begin + tile * a.tile_dirs;
+    if (tile_begin >= a.dir_end) return;
+    const int tile_end = min(tile_begin + a.tile_dirs, a.dir_end);
+    const int M = a.n_mics, N = a.n_samples;                   // M % 16 == 0, N % 4 == 0, N <= 256 (plan_das)
+    const int n_half = M / HC;
+    const float* __restrict__ sig0 = signals + (size_t)f0 * a.m_total * N;
+    const float* __restrict__ sig1 = signals + (size_t)f1 * a.m_total * N;
+    float* __restrict__ img0 = images + (size_t)f0 * a.image_stride;
+    float* __restrict__ img1 = images + (size_t)f1 * a.image_stride;
+    const int32_t* __restrict__ dig = reinterpret_cast<const int32_t*>(taps);   // the digest rides in the unused `taps` slot
+
+    // Staging: waves w and w + 8 share mic (w & 7) of every half (both fetch its two frames): part 0 writes the sample rows
+    // (lerp) / copy 0 (pad), part 1 the difference rows (lerp) / copy 1 (pad).  Lane c holds half c's mic id (first 64 halves).
+    const int my_mic = wave & 7, part = wave >> 3;
+    const int vmic = (lane < n_half) ? mics[lane * HC + my_mic] : 0;
+    struct Staged2 { float4 v0, v1; };
+    auto fetch = [&](int h) -> Staged2 {
+        const int mic = (h < kWave) ? __builtin_amdgcn_readlane(vmic, h) : mics[h * HC + my_mic];
+        Staged2 st;
+        st.v0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        st.v1 = st.v0;
+        if (4 * lane < N) {
+            st.v0 = *reinterpret_cast<const float4*>(sig0 + (size_t)mic * N + 4 * lane);
+            st.v1 = *reinterpret_cast<const float4*>(sig1 + (size_t)mic * N + 4 * lane);
+        }
+        return st;
+    };
+    // rows of a mic: [s copy 0][s copy 1] ([d copy 0][d copy 1]); copy c holds sample i - c at position i; position i = floats 2 i, 2 i + 1
+    auto write_row = [&](float* row, const float4 x0, const float4 x1, float p0, float p1, bool shifted) {
+        float4* q = reinterpret_cast<float4*>(row + 2 * LEAD) + 2 * lane;
+        if (!shifted) {
+            q[0] = make_float4(x0.x, x1.x, x0.y, x1.y);
+            q[1] = make_float4(x0.z, x1.z, x0.w, x1.w);
+        } else {
+            q[0] = make_float4(p0, p1, x0.x, x1.x);
+            q[1] = make_float4(x0.y, x1.y, x0.z, x1.z);
+        }
+    };
+    auto stage = [&](int h, const Staged2& st, bool wipe) {
+        float* slot = lds + ((h & 1) * HC + my_mic) * G::kSlot;
+        float4 x0 = st.v0, x1 = st.v1;
+        float* rows;                                            // the two rows this wave writes
+        bool both_copies = true;
+        if constexpr (kLerp) {
+            rows = slot + part * C * RS;
+            if (part == 1) {
+                // D[i] = s[i+1] - s[i], the reference's own subtraction (lerp_and_sum.c:54); D[-1] stays 0 (prefix)
+                const float n0 = dpp_next(x0.x), n1 = dpp_next(x1.x);
+                x0 = make_float4(x0.y - x0.x, x0.z - x0.y, x0.w - x0.z, n0 - x0.w);
+                x1 = make_float4(x1.y - x1.x, x1.z - x1.y, x1.w - x1.z, n1 - x1.w);
+            }
+        } else {
+            rows = slot + part * RS;                            // pad: one copy per wave
+            both_copies = false;
+        }
+        const float p0 = dpp_prev(x0.w), p1 = dpp_prev(x1.w);   // the previous lane's last sample (0 in lane 0: the prefix)
+        if (both_copies) {
+            write_row(rows, x0, x1, p0, p1, false);
+            write_row(rows + RS, x0, x1, p0, p1, true);
+        } else {
+            write_row(rows, x0, x1, p0, p1, part == 1);
+        }
+        if (wipe) {
+            // the zero prefix (56 samples x 2 frames = 28 quads per row): only the parked rows of the power pass overwrite it
+            constexpr int PQ = LEAD >> 1;
+            static_assert(2 * PQ <= kWave, "one lane per prefix quad of two rows");
+            if (both_copies) {
+                if (lane < 2 * PQ) reinterpret_cast<float4*>(rows + (lane / PQ) * RS)[lane % PQ] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                if (lane < PQ) reinterpret_cast<float4*>(rows)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+
+    Staged2 st = fetch(0);
+    const int lb = 16 * lane + (int)(unsigned)(size_t)((__attribute__((address_space(3))) char*)lds);
+
+    for (int g0 = tile_begin; g0 < tile_end; g0 += kGroup) {
+        f32x2 acc[DW][4];                                       // (frame 0, frame 1) of samples 2l, 2l+1, 128+2l, 128+2l+1
+#pragma unroll
+        for (int j = 0; j < DW; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[j][q] = f32x2{0.0f, 0.0f};
+
+        __syncthreads();   // the previous group's parked rows have been summed
+        stage(0, st, true);
+        st = fetch(1 % n_half);
+        __syncthreads();
+
+        const int dw0 = g0 + wave * DW;                         // wave-uniform
+        const bool busy = dw0 < tile_end;
+        const size_t grp = busy ? (size_t)(dw0 - a.dir_begin) / DW : 0;
+        for (int h = 0; h < n_half; ++h) {
+            if (h + 1 < n_half) {
+                stage(h + 1, st, h == 0);                       // into the half whose sweeps ended before the last barrier
+                if (h + 2 < n_half) st = fetch(h + 2);
+                else if (g0 + kGroup < tile_end) st = fetch(0);
+            }
+            if (busy) {
+                const int32_t* __restrict__ et = dig + (grp * M + (size_t)h * HC) * DW;
+                const float* __restrict__ ht = reinterpret_cast<const float*>(dig) + a.digest_h_off + (grp * M + (size_t)h * HC) * DW;
+                struct Entries { int e[DW]; unsigned long long hp[DW / 2]; };
+                auto request = [&](Entries& t, int m) {
+                    // (reads past the half's last mic stay inside the slack-padded table and are dropped)
+#pragma unroll
+                    for (int j = 0; j < DW; ++j) t.e[j] = et[m * DW + j];
+#pragma unroll
+                    for (int j = 0; j < DW / 2; ++j) {
+                        t.hp[j] = 0;
+                        if constexpr (kLerp) t.hp[j] = *reinterpret_cast<const unsigned long long*>(ht + m * DW + 2 * j);
+                    }
+                };
+                Entries E[3];
+                request(E[0], 0);
+                request(E[1], 1);
+                auto mic = [&](int m, auto kc) {
+                    constexpr int K = decltype(kc)::value, K2 = (K + 2) % 3;
+                    const Entries& cur = E[K];
+                    pair2_first<ALGO>(acc, cur.e[0], cur.hp[0], lb);
+                    request(E[K2], m + 2);      // after the first statement's wait, so that it does not sit on these loads
+                    pair2_rest<ALGO>(acc, cur.e, cur.hp, lb);
+                };
+                using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+                static_assert(HC == 8, "eight mics: two trips of three and two more");
+#pragma unroll 1
+                for (int t = 0; t < 2; ++t) {
+                    mic(0, I0{}); mic(1, I1{}); mic(2, I2{});
+                    et += 3 * DW; ht += 3 * DW;
+                }
+                mic(0, I0{});
+                mic(1, I1{});
+                __builtin_amdgcn_s_waitcnt(0xC07F);             // the entries requested past the half's end have landed (and are dropped)
+            }
+            __syncthreads();   // half h is free, half h + 1 is staged
+        }
+
+        // ---- k-ordered mean power (pad_and_sum.c:120-128), one frame at a time: the 16 waves park the squared means of their
+        // directions (row = direction, k in order; the rows alias the LDS image), then one direction per lane runs the sequential sum.
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            if (f == 1) __syncthreads();        // frame 0's rows have been summed
+            auto park = [&](auto mul_c) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < DW; ++j) {
+                    float* row = lds + (wave * DW + j) * kPark;
+                    const float x0 = f == 0 ? acc[j][0].x : acc[j][0].y, x1 = f == 0 ? acc[j][1].x : acc[j][1].y;
+                    const float x2 = f == 0 ? acc[j][2].x : acc[j][2].y, x3 = f == 0 ? acc[j][3].x : acc[j][3].y;
+                    float o0, o1, o2, o3;
+                    if constexpr (decltype(mul_c)::value) {
+                        o0 = x0 * a.inv_n; o1 = x1 * a.inv_n; o2 = x2 * a.inv_n; o3 = x3 * a.inv_n;
+                    } else {
+                        float fm = (float)M;
+                        asm volatile("" : "+v"(fm));   // not speculatable: keeps this path behind its branch
+                        o0 = x0 / fm; o1 = x1 / fm; o2 = x2 / fm; o3 = x3 / fm;
+                    }
+                    reinterpret_cast<float2*>(row)[lane] = make_float2(o0 * o0, o1 * o1);             // samples 2l, 2l+1
+                    reinterpret_cast<float2*>(row + 128)[lane] = make_float2(o2 * o2, o3 * o3);       // samples 128+2l, 128+2l+1
+                }
+            };
+            if (__builtin_expect(a.n_is_pow2, 1)) park(std::true_type{}); else park(std::false_type{});
+            __syncthreads();
+            const int g = wave * kWave + lane;            // parked row of this lane
+            const int d = g0 + g;
+            if (g < kGroup && d < tile_end && (f == 0 || two)) {
+                const float* row = lds + g * kPark;
+                const float4* row4 = reinterpret_cast<const float4*>(row);
+                float sum = 0.0f;
+                int k = 0;
+                for (; k + 32 <= N; k += 32) {
+                    float4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = row4[(k >> 2) + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { sum += v[u].x; sum += v[u].y; sum += v[u].z; sum += v[u].w; }
+                }
+                for (; k < N; ++k) sum += row[k];
+                (f == 0 ? img0 : img1)[d - a.image_origin] = sum / (float)N;
+            }
+        }
+    }
+}
 
 // ==================================================================================================
 // Hybrid beamformer (integer delay + 8-tap fractional FIR, hybrid_convolve_and_sum.c:51-121), two frames per workgroup.
@@ -2484,8 +2773,18 @@ hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, in
             if constexpr (!kFir && NSEG == 1) {
                 if (plan.nf == 2) {
                     if (L.tab.digest == nullptr || L.tab.digest_direct || plan.waves != copies::kWaves || plan.mic_chunk != copies::PairGeo<ALGO>::kMc ||
-                        plan.row_stride != copies::PairGeo<ALGO>::kRs || plan.lead != copies::PairGeo<ALGO>::kLead || (L.n_mics % 16) != 0)
+                        (!plan.interleaved && plan.row_stride != copies::PairGeo<ALGO>::kRs) || plan.lead != copies::PairGeo<ALGO>::kLead || (L.n_mics % 16) != 0)
                         return hipErrorInvalidValue;
+                    if (plan.interleaved) {
+                        if (plan.row_stride != copies::Pair2Geo<ALGO>::kRs) return hipErrorInvalidValue;
+                        auto kernel2 = copies::das_pair2_kernel<ALGO>;
+                        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
+                        if (e2 != hipSuccess) return e2;
+                        const dim3 grid2((unsigned)plan.n_tiles * (unsigned)((frames + 1) / 2));
+                        hipLaunchKernelGGL(kernel2, grid2, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole, L.tab.frac,
+                                           reinterpret_cast<const float*>(L.tab.digest), a);
+                        return hipGetLastError();
+                    }
                     auto kernel = copies::das_pair_kernel<ALGO>;
                     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
                     if (e != hipSuccess) return e;
@@ -2732,6 +3031,12 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
             (L.n_samples % 4) == 0 && L.frames >= 2 && !(L.debug & 16)) {
             p.nf = 2;
             mc = 16;
+            // frames interleaved in the rows (das_pair2_kernel) for lerp: 4 instead of 8 LDS reads per (re)load, +1.5 %; pad reads
+            // half as much to begin with and measured 2 % slower that way  (debug bit 15: A/B switch, the other kernel)
+            if ((L.algo == ALGO_LERP) != ((L.debug & 32768) != 0)) {
+                p.interleaved = 1;
+                p.row_stride = 2 * copies::Geo<1>::kRs;         // the two frames of a mic share a row, sample by sample
+            }
         }
         // The hybrid beamformer's two-frame sweep (das_hybrid_pair_kernel) under the same conditions.  (debug bit 13: A/B switch)
         if (L.algo == ALGO_HYBRID && nseg == 1 && L.n_taps == 8 && waves == copies::kWaves && p.lead == fixed_lead && (L.n_mics % 16) == 0 &&
@@ -2740,6 +3045,7 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
             mc = copies::HybridGeo::kMc;                        // 32 mic slots: two frames interleaved per row, two shifted copies
             p.copies = copies::HybridGeo::kC;
             p.row_stride = copies::HybridGeo::kRs;
+            p.interleaved = 1;
         }
         const bool hybrid_pair = L.algo == ALGO_HYBRID && p.nf == 2;
         // Long rows (2 / 4 segments): das_long_kernel where its LDS image -- two halves of 16 / nseg mics -- fits and the mic count is
@@ -2839,7 +3145,7 @@ hipError_t launch_digest(const DasLaunch& L, const DasPlan& plan, int32_t* d_dig
     // s[k - p - 1 - T/2] (T = 8)
     // (`arrays`: rows of one staged mic in units of its shifted copies -- samples, lerp's differences, and both frames of the pair kernel)
     // (the hybrid pair kernel interleaves its two frames inside a row: one array per mic)
-    const int arrays = ((L.algo == ALGO_LERP) ? 2 : 1) * ((plan.nf == 2 && L.algo != ALGO_HYBRID) ? 2 : 1), bias = (L.algo == ALGO_LERP) ? 1 : (L.algo == ALGO_HYBRID) ? 5 : 0;
+    const int arrays = ((L.algo == ALGO_LERP) ? 2 : 1) * ((plan.nf == 2 && !plan.interleaved) ? 2 : 1), bias = (L.algo == ALGO_LERP) ? 1 : (L.algo == ALGO_HYBRID) ? 5 : 0;
     if ((L.algo == ALGO_HYBRID && plan.nf != 2) || direct) {
         hipLaunchKernelGGL(digest_kernel, dim3(1024), dim3(256), 0, stream, L.tab.whole, d_digest, (long long)L.n_dirs * L.n_mics, L.n_mics, plan.mic_chunk,
                            arrays, plan.row_stride, plan.lead, bias, plan.copies);
@@ -2847,7 +3153,7 @@ hipError_t launch_digest(const DasLaunch& L, const DasPlan& plan, int32_t* d_dig
         const long long entries = grouped_entries(L, plan);
         hipLaunchKernelGGL(digest_grouped_kernel, dim3(1024), dim3(256), 0, stream, L.tab.whole, L.algo == ALGO_LERP ? L.tab.frac : nullptr, d_digest,
                            entries, entries, L.n_mics, plan.dpw, L.dir_begin, L.dir_end, plan.mic_chunk, arrays, plan.row_stride, plan.lead, bias,
-                           plan.copies, d_reload_count, L.algo == ALGO_HYBRID ? 1 : 0);
+                           plan.copies, d_reload_count, L.algo == ALGO_HYBRID ? 1 : 0, plan.interleaved ? 2 : 1);
     }
     return hipGetLastError();
 }
