@@ -315,7 +315,7 @@ bool plan_or_error(bf::DasLaunch& L, bf::DasPlan* plan)
 // Shifted-copies layout with scalar tables: make sure the table set carries a digest built for this plan.
 bool ensure_digest(TableSet& t, bf::DasLaunch& L, bf::DasPlan& plan, hipStream_t stream)
 {
-    S().last_variant = plan.layout == 2 ? 4 : plan.layout;          // refined below for the digest-driven kernels
+    S().last_variant = plan.layout == 2 ? (plan.nf == 2 ? 7 : 4) : plan.layout;   // refined below for the digest-driven kernels
     if (plan.layout != 2 || L.algo == bf::ALGO_FIR_NAIVE || L.algo == bf::ALGO_FIR_VEC) return true;   // the plain FIRs have no whole-sample table
     // everything the digest depends on: the plan's geometry, the algorithm and (grouped layouts) the direction range
     const DigestKey key{true, plan.mic_chunk, plan.row_stride, plan.lead, L.algo, plan.dpw, L.dir_begin, L.dir_end, L.n_mics, plan.nf};

@@ -2298,12 +2298,71 @@ __device__ __forceinline__ void hybrid_step(f32x2 (&o)[4], const f32x4 (&Q)[6], 
           [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3), [w4] "v"(w4), [w5] "v"(w5), [w6] "v"(w6), [w7] "v"(w7), [w8] "v"(w8), [w9] "v"(w9),
           [w10] "v"(w10));
 }
+// The plain 8-tap FIR (convolve_and_sum.c:197-211, mimo_convolve_naive): the same chains without a guard
+__device__ __forceinline__ void fir_naive_step(f32x2 (&o)[4], const f32x4 (&Q)[6], const unsigned long long (&h)[4])
+{
+    const f32x2 w0 = __builtin_shufflevector(Q[0], Q[0], 0, 1), w1 = __builtin_shufflevector(Q[0], Q[0], 2, 3);
+    const f32x2 w2 = __builtin_shufflevector(Q[1], Q[1], 0, 1), w3 = __builtin_shufflevector(Q[1], Q[1], 2, 3);
+    const f32x2 w4 = __builtin_shufflevector(Q[2], Q[2], 0, 1), w5 = __builtin_shufflevector(Q[2], Q[2], 2, 3);
+    const f32x2 w6 = __builtin_shufflevector(Q[3], Q[3], 0, 1), w7 = __builtin_shufflevector(Q[3], Q[3], 2, 3);
+    const f32x2 w8 = __builtin_shufflevector(Q[4], Q[4], 0, 1), w9 = __builtin_shufflevector(Q[4], Q[4], 2, 3);
+    const f32x2 w10 = __builtin_shufflevector(Q[5], Q[5], 0, 1);
+    asm volatile(
+        BF_H_OUT(0, 0, 1, 2, 3, 4, 5, 6, 7) BF_H_OUT(1, 1, 2, 3, 4, 5, 6, 7, 8) BF_H_OUT(2, 2, 3, 4, 5, 6, 7, 8, 9) BF_H_OUT(3, 3, 4, 5, 6, 7, 8, 9, 10)
+        : [o0] "+v"(o[0]), [o1] "+v"(o[1]), [o2] "+v"(o[2]), [o3] "+v"(o[3])
+        : [h01] "s"(h[0]), [h23] "s"(h[1]), [h45] "s"(h[2]), [h67] "s"(h[3]),
+          [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3), [w4] "v"(w4), [w5] "v"(w5), [w6] "v"(w6), [w7] "v"(w7), [w8] "v"(w8), [w9] "v"(w9),
+          [w10] "v"(w10));
+}
+// The AVX2 flavour (convolve_and_sum.c:158-192 + sum8 :132-153, mimo_convolve_vectorized) with one block of 8 taps: eight plain
+// products p_t = x[t] * h[t] (the fma lanes start from 0), then the fixed tree ((p0 + p4) + (p2 + p6)) + ((p1 + p5) + (p3 + p7)), out +=.
+#define BF_V_MUL(p, hh, w, MODS) "v_pk_mul_f32 %[" #p "], %[" #hh "], %[w" #w "] " MODS "\n\t"
+#define BF_V_OUT(j, w0, w1, w2, w3, w4, w5, w6, w7)                                                                             \
+    BF_V_MUL(p0, h01, w0, "op_sel_hi:[0,1]") BF_V_MUL(p1, h01, w1, "op_sel:[1,0] op_sel_hi:[1,1]")                                \
+    BF_V_MUL(p2, h23, w2, "op_sel_hi:[0,1]") BF_V_MUL(p3, h23, w3, "op_sel:[1,0] op_sel_hi:[1,1]")                                \
+    BF_V_MUL(p4, h45, w4, "op_sel_hi:[0,1]") BF_V_MUL(p5, h45, w5, "op_sel:[1,0] op_sel_hi:[1,1]")                                \
+    BF_V_MUL(p6, h67, w6, "op_sel_hi:[0,1]") BF_V_MUL(p7, h67, w7, "op_sel:[1,0] op_sel_hi:[1,1]")                                \
+    "v_pk_add_f32 %[p0], %[p0], %[p4]\n\tv_pk_add_f32 %[p1], %[p1], %[p5]\n\tv_pk_add_f32 %[p2], %[p2], %[p6]\n\tv_pk_add_f32 %[p3], %[p3], %[p7]\n\t" \
+    "v_pk_add_f32 %[p0], %[p0], %[p2]\n\tv_pk_add_f32 %[p1], %[p1], %[p3]\n\tv_pk_add_f32 %[p0], %[p0], %[p1]\n\t"                   \
+    "v_pk_add_f32 %[o" #j "], %[o" #j "], %[p0]\n\t"
+__device__ __forceinline__ void fir_vec_step(f32x2 (&o)[4], const f32x4 (&Q)[6], const unsigned long long (&h)[4])
+{
+    const f32x2 w0 = __builtin_shufflevector(Q[0], Q[0], 0, 1), w1 = __builtin_shufflevector(Q[0], Q[0], 2, 3);
+    const f32x2 w2 = __builtin_shufflevector(Q[1], Q[1], 0, 1), w3 = __builtin_shufflevector(Q[1], Q[1], 2, 3);
+    const f32x2 w4 = __builtin_shufflevector(Q[2], Q[2], 0, 1), w5 = __builtin_shufflevector(Q[2], Q[2], 2, 3);
+    const f32x2 w6 = __builtin_shufflevector(Q[3], Q[3], 0, 1), w7 = __builtin_shufflevector(Q[3], Q[3], 2, 3);
+    const f32x2 w8 = __builtin_shufflevector(Q[4], Q[4], 0, 1), w9 = __builtin_shufflevector(Q[4], Q[4], 2, 3);
+    const f32x2 w10 = __builtin_shufflevector(Q[5], Q[5], 0, 1);
+    f32x2 p0, p1, p2, p3, p4, p5, p6, p7;
+    asm volatile(
+        BF_V_OUT(0, 0, 1, 2, 3, 4, 5, 6, 7) BF_V_OUT(1, 1, 2, 3, 4, 5, 6, 7, 8) BF_V_OUT(2, 2, 3, 4, 5, 6, 7, 8, 9) BF_V_OUT(3, 3, 4, 5, 6, 7, 8, 9, 10)
+        : [o0] "+v"(o[0]), [o1] "+v"(o[1]), [o2] "+v"(o[2]), [o3] "+v"(o[3]), [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2), [p3] "=&v"(p3),
+          [p4] "=&v"(p4), [p5] "=&v"(p5), [p6] "=&v"(p6), [p7] "=&v"(p7)
+        : [h01] "s"(h[0]), [h23] "s"(h[1]), [h45] "s"(h[2]), [h67] "s"(h[3]),
+          [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3), [w4] "v"(w4), [w5] "v"(w5), [w6] "v"(w6), [w7] "v"(w7), [w8] "v"(w8), [w9] "v"(w9),
+          [w10] "v"(w10));
+}
+#undef BF_V_MUL
+#undef BF_V_OUT
 #undef BF_H_OUT
 #undef BF_H_E
 #undef BF_H_O
+// a mic's window for the plain FIRs: read in place, no guard
+__device__ __forceinline__ void fir_window_first(f32x4 (&Q)[6], int ec, int lbase)
+{
+    int ad;
+    asm volatile("v_add_u32 %[ad], %[ec], %[lb]\n\t"
+                 "ds_read_b128 %[q0], %[ad] offset:0\n\tds_read_b128 %[q1], %[ad] offset:16\n\tds_read_b128 %[q2], %[ad] offset:32\n\t"
+                 "ds_read_b128 %[q3], %[ad] offset:48\n\tds_read_b128 %[q4], %[ad] offset:64\n\tds_read_b128 %[q5], %[ad] offset:80\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : [q0] "=&v"(Q[0]), [q1] "=&v"(Q[1]), [q2] "=&v"(Q[2]), [q3] "=&v"(Q[3]), [q4] "=&v"(Q[4]), [q5] "=&v"(Q[5]), [ad] "=&v"(ad)
+                 : [ec] "s"(ec), [lb] "v"(lbase));
+}
 
+template <int ALGO>
 __global__ void __launch_bounds__(1024, 4) das_hybrid_pair_kernel(BF_TABLE_PARAMS, KArgs a)
 {
+    constexpr bool kHybrid = ALGO == ALGO_HYBRID;
     using G = HybridGeo;
     constexpr int C = G::kC, RS = G::kRs, LEAD = G::kLead, HC = G::kHalf, W = 16, DW = 8, kGroup = DW * W, kPark = Geo<1>::kPark;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2391,8 +2450,8 @@ __global__ void __launch_bounds__(1024, 4) das_hybrid_pair_kernel(BF_TABLE_PARAM
             }
             if (busy) {
                 const int m0 = h * HC;
-                const int32_t* __restrict__ et = dig + (grp * M + m0) * DW;                       // LDS offsets, 8 per mic
-                const int32_t* __restrict__ nt = dig + a.digest_h_off + (grp * M + m0) * DW;      // packed guards, 8 per mic
+                const int32_t* __restrict__ et = dig + (kHybrid ? (grp * M + m0) * DW : 0);       // LDS offsets, 8 per mic (hybrid only)
+                const int32_t* __restrict__ nt = dig + (kHybrid ? a.digest_h_off + (grp * M + m0) * DW : 0);   // packed guards, 8 per mic
                 // taps [D][M][8]: one row pointer per direction of the wave (directions past the end repeat the last one)
                 const unsigned long long* __restrict__ tp[DW];
 #pragma unroll
@@ -2415,17 +2474,23 @@ __global__ void __launch_bounds__(1024, 4) das_hybrid_pair_kernel(BF_TABLE_PARAM
 #pragma unroll
                 for (int q = 0; q < 6; ++q) Q[q] = f32x4{0.f, 0.f, 0.f, 0.f};
                 KM.m[0] = KM.m[1] = KM.m[2] = KM.m[3] = 0ull;
-                request(E[0], 0);
+                if constexpr (kHybrid) request(E[0], 0);
                 request_taps(T[0], std::integral_constant<int, 0>{}, 0);
                 request_taps(T[1], std::integral_constant<int, 1>{}, 0);
                 // steps (m, j) in order; the taps of step s = 8 m + j live in set s % 3 and are requested two steps ahead;
                 // 8 % 3 == 2, so the sets of mic m start at (2 m) % 3: three mics until the pattern repeats
+                int m0s = 0;                                    // mic (inside the half) the current trip starts at
                 auto mic = [&](int m, auto pc, auto rc) {
                     constexpr int P = decltype(pc)::value, R = decltype(rc)::value;    // entry set, first taps set
                     const Entries& cur = E[P];
                     __builtin_amdgcn_s_waitcnt(0xC07F);
-                    hybrid_window_first(Q, KM, cur.e[0], cur.n[0], lb);
-                    request(E[P ^ 1], m + 1);                   // (past the half's last mic: inside the slack-padded table, dropped)
+                    if constexpr (kHybrid) {
+                        hybrid_window_first(Q, KM, cur.e[0], cur.n[0], lb);
+                        request(E[P ^ 1], m + 1);               // (past the half's last mic: inside the slack-padded table, dropped)
+                    } else {
+                        // no whole-sample delay: every direction reads the window that starts T/2 = 4 samples back (copy 0)
+                        fir_window_first(Q, (((h & 1) * HC + (m0s + m)) * G::kSlot + 2 * (LEAD - 4)) * 4, lb);
+                    }
                     auto stepj = [&](auto jc) {
                         constexpr int j = decltype(jc)::value;
                         // Scalar loads return out of order, so "this step's taps have landed" can only be a full wait -- placed
@@ -2434,8 +2499,14 @@ __global__ void __launch_bounds__(1024, 4) das_hybrid_pair_kernel(BF_TABLE_PARAM
                         if constexpr (j > 0) __builtin_amdgcn_s_waitcnt(0xC07F);
                         if constexpr (j + 2 < DW) request_taps(T[(R + j + 2) % 3], std::integral_constant<int, j + 2>{}, m);
                         else request_taps(T[(R + j + 2) % 3], std::integral_constant<int, j + 2 - DW>{}, m + 1);
-                        if constexpr (j > 0) hybrid_window(Q, KM, cur.e[j - 1], cur.e[j], cur.n[j], lb);
-                        hybrid_step(acc[j], Q, T[(R + j) % 3].h, KM);
+                        if constexpr (kHybrid) {
+                            if constexpr (j > 0) hybrid_window(Q, KM, cur.e[j - 1], cur.e[j], cur.n[j], lb);
+                            hybrid_step(acc[j], Q, T[(R + j) % 3].h, KM);
+                        } else if constexpr (ALGO == ALGO_FIR_NAIVE) {
+                            fir_naive_step(acc[j], Q, T[(R + j) % 3].h);
+                        } else {
+                            fir_vec_step(acc[j], Q, T[(R + j) % 3].h);
+                        }
                     };
                     stepj(std::integral_constant<int, 0>{}); stepj(std::integral_constant<int, 1>{});
                     stepj(std::integral_constant<int, 2>{}); stepj(std::integral_constant<int, 3>{});
@@ -2447,7 +2518,7 @@ __global__ void __launch_bounds__(1024, 4) das_hybrid_pair_kernel(BF_TABLE_PARAM
 #pragma unroll 1
                 for (int t = 0; t < 2; ++t) {                   // 6 mics per trip: entry sets alternate, taps sets repeat after 3 mics
                     mic(0, I0{}, I0{}); mic(1, I1{}, I2{}); mic(2, I0{}, I1{}); mic(3, I1{}, I0{}); mic(4, I0{}, I2{}); mic(5, I1{}, I1{});
-                    et += 6 * DW; nt += 6 * DW;
+                    et += 6 * DW; nt += 6 * DW; m0s += 6;
 #pragma unroll
                     for (int j = 0; j < DW; ++j) tp[j] += 6 * 4;
                 }
@@ -2802,18 +2873,18 @@ hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, in
                     return hipGetLastError();
                 }
             }
-            if constexpr (ALGO == ALGO_HYBRID) {
-                if (plan.nf == 2) {                             // das_hybrid_pair_kernel
+            if constexpr (kFir) {
+                if (plan.nf == 2) {                             // das_hybrid_pair_kernel<hybrid | fir_naive | fir_vec>
                     using HG = copies::HybridGeo;
-                    if (L.tab.digest == nullptr || plan.waves != copies::kWaves || plan.mic_chunk != HG::kMc || plan.row_stride != HG::kRs ||
+                    if ((ALGO == ALGO_HYBRID && L.tab.digest == nullptr) || plan.waves != copies::kWaves || plan.mic_chunk != HG::kMc || plan.row_stride != HG::kRs ||
                         plan.lead != HG::kLead || (L.n_mics % 16) != 0 || L.n_taps != 8)
                         return hipErrorInvalidValue;
-                    auto kernel = copies::das_hybrid_pair_kernel;
+                    auto kernel = copies::das_hybrid_pair_kernel<ALGO>;
                     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
                     if (e != hipSuccess) return e;
                     const dim3 pair_grid((unsigned)plan.n_tiles * (unsigned)((frames + 1) / 2));
                     hipLaunchKernelGGL(kernel, pair_grid, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole,
-                                       reinterpret_cast<const float*>(L.tab.digest), L.tab.taps, a);
+                                       ALGO == ALGO_HYBRID ? reinterpret_cast<const float*>(L.tab.digest) : L.tab.frac, L.tab.taps, a);
                     return hipGetLastError();
                 }
             }
@@ -3039,7 +3110,7 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
             }
         }
         // The hybrid beamformer's two-frame sweep (das_hybrid_pair_kernel) under the same conditions.  (debug bit 13: A/B switch)
-        if (L.algo == ALGO_HYBRID && nseg == 1 && L.n_taps == 8 && waves == copies::kWaves && p.lead == fixed_lead && (L.n_mics % 16) == 0 &&
+        if (fir && nseg == 1 && L.n_taps == 8 && waves == copies::kWaves && p.lead == fixed_lead && (L.n_mics % 16) == 0 &&
             (L.n_samples % 4) == 0 && L.frames >= 2 && !(L.debug & 8192)) {
             p.nf = 2;
             mc = copies::HybridGeo::kMc;                        // 32 mic slots: two frames interleaved per row, two shifted copies
@@ -3047,7 +3118,7 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
             p.row_stride = copies::HybridGeo::kRs;
             p.interleaved = 1;
         }
-        const bool hybrid_pair = L.algo == ALGO_HYBRID && p.nf == 2;
+        const bool hybrid_pair = fir && p.nf == 2;
         // Long rows (2 / 4 segments): das_long_kernel where its LDS image -- two halves of 16 / nseg mics -- fits and the mic count is
         // a whole number of halves.  (debug bit 12: A/B switch back to das_copies_kernel)
         p.long_rows = 0;
