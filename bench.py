@@ -380,7 +380,7 @@ def main():
             "roofline": {"bound": "valu", "achieved": valu_achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s (fp32; peak = 157.3 TFLOP/s / 2)",
                          "frac": valu_achieved / VALU_PEAK_TLANEOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": {5: "copies::das_pair_kernel<%s>", 2: "copies::das_copies_kernel<%s>", 3: "copies::das_copies_kernel<%s, DIRECT>",
-                                    4: "copies::das_copies_kernel<%s>", 6: "copies::das_long_kernel<%s>", 7: "copies::das_hybrid_pair_kernel (%s)"}.get(nat.lib.bf_last_das_variant(), "das_mimo_kernel<%s>") % args.algo,
+                                    4: "copies::das_copies_kernel<%s>", 6: "copies::das_long_kernel<%s>", 7: "copies::das_hybrid_pair_kernel<%s>", 8: "copies::das_pair2_kernel<%s>"}.get(nat.lib.bf_last_das_variant(), "das_mimo_kernel<%s>") % args.algo,
                          "kernel_ms": kernel_ms, "gmacs_per_s": macs / (kernel_ms * 1e-3) / 1e9,
                          "note": "gather-accumulate kernel, no MFMA: tables stay L2-resident across the frames of a launch and sample quads are "
                                  "re-read from LDS only when a direction's delay differs from its neighbour's, so HBM is nearly idle and the "

@@ -131,7 +131,7 @@ int bf_gpu_available(void);
  * (direction-outer, chosen for tables without structure), 4 shifted copies (8-tap FIR), 5 shifted copies (sweep, two
  * frames per workgroup: batched launches of pad / lerp), 6 shifted copies for long blocks (256 < N_SAMPLES <= 1024: LDS image in
  * two halves, conflict-free lane mapping), 7 hybrid sweep with shared windows, two frames per workgroup (batched launches of the
- * hybrid beamformer); -1 before the first launch. */
+ * 8-tap FIR flavours), 8 the two-frame sweep on frame-interleaved rows (batched lerp); -1 before the first launch. */
 int bf_last_das_variant(void);
 /* Planner A/B switches (the bits of $BF_DEBUG, das_kernels.hip plan_das) at run time, for tests and profiling; -1 returns to
  * the environment's value. */

@@ -308,7 +308,7 @@ def test_batched_device_path(nat, algo):
     assert nat.lib.bf_das_device(ALGOS[algo], d_sig.data_ptr(), M, d_img.data_ptr(), D, F, nat.iptr(mics), M, 0, D, stream) == 0
     torch.cuda.synchronize()
     assert np.array_equal(d_img.cpu().numpy(), ref_imgs)
-    assert nat.lib.bf_last_das_variant() == 5          # geometric tables, a batch: the sweep with shared reads, two frames per workgroup
+    assert nat.lib.bf_last_das_variant() == (8 if algo == "lerp" else 5)   # geometric tables, a batch: the two-frame sweep (lerp: frame-interleaved rows)
     # two direction shards, as two ranks would compute them
     cut = 5003
     lo = torch.full((F, cut), float("nan"), dtype=torch.float32, device="cuda")
@@ -341,7 +341,7 @@ def test_batched_frame_pairs(nat, oracle_lib, algo, cfg, n_active, F):
     assert nat.lib.bf_das_device(ALGOS[algo], d_sig.data_ptr(), M, d_img.data_ptr(), D, F, nat.iptr(mics), n_active, 0, D,
                                  torch.cuda.current_stream().cuda_stream) == 0, nat.check()
     torch.cuda.synchronize()
-    assert nat.lib.bf_last_das_variant() == 5
+    assert nat.lib.bf_last_das_variant() == (8 if algo == "lerp" else 5)
     got = d_img.cpu().numpy()
     assert np.array_equal(got[F - 1], one.reshape(-1))
     for f in range(F):
@@ -413,7 +413,7 @@ def test_batched_frame_pairs_short_block(nat, oracle_lib, algo):
         assert nat.lib.bf_das_device(ALGOS[algo], d_sig.data_ptr(), M, d_img.data_ptr(), D, F, nat.iptr(mics), M, 0, D,
                                      torch.cuda.current_stream().cuda_stream) == 0, nat.check()
         torch.cuda.synchronize()
-        assert nat.lib.bf_last_das_variant() == 5
+        assert nat.lib.bf_last_das_variant() == (8 if algo == "lerp" else 5)
         got = d_img.cpu().numpy()
         for f in range(F):
             assert np.array_equal(got[f], orc.mimo_range(ALGOS[algo], frames[f], mics, 0, D).reshape(-1)), f

@@ -349,7 +349,7 @@ bool ensure_digest(TableSet& t, bf::DasLaunch& L, bf::DasPlan& plan, hipStream_t
     }
     L.tab.digest_direct = t.digest_direct;
     L.tab.digest = t.digest.p;
-    S().last_variant = (L.algo == bf::ALGO_PAD || L.algo == bf::ALGO_LERP) ? (t.digest_direct ? 3 : plan.nf == 2 ? 5 : plan.long_rows ? 6 : 2) : plan.nf == 2 ? 7 : 4;
+    S().last_variant = (L.algo == bf::ALGO_PAD || L.algo == bf::ALGO_LERP) ? (t.digest_direct ? 3 : plan.nf == 2 ? (plan.interleaved ? 8 : 5) : plan.long_rows ? 6 : 2) : plan.nf == 2 ? 7 : 4;
     return true;
 }
 

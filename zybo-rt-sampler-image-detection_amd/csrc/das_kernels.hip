@@ -2016,7 +2016,7 @@ __global__ void __launch_bounds__(1024, 4) das_pair2_kernel(BF_TABLE_PARAMS, KAr
     constexpr bool kLerp = G::kLerp;
     constexpr int A = G::kA, C = G::kC, RS = G::kRs, LEAD = G::kLead, HC = G::kHalf, W = 16, DW = 8, kGroup = DW * W, kPark = Geo<1>::kPark;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & (kWave - 1);
+    const int lane_ = threadIdx.x & (kWave - 1), lane = lane_;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int tile, fpair;
     tile_and_frame(a, &tile, &fpair);
@@ -2051,7 +2051,7 @@ __global__ void __launch_bounds__(1024, 4) das_pair2_kernel(BF_TABLE_PARAMS, KAr
         return st;
     };
     // rows of a mic: [s copy 0][s copy 1] ([d copy 0][d copy 1]); copy c holds sample i - c at position i; position i = floats 2 i, 2 i + 1
-    auto write_row = [&](float* row, const float4 x0, const float4 x1, float p0, float p1, bool shifted) {
+    auto write_row = [&](float* row, const float4 x0, const float4 x1, float p0, float p1, bool shifted, int lane) {
         float4* q = reinterpret_cast<float4*>(row + 2 * LEAD) + 2 * lane;
         if (!shifted) {
             q[0] = make_float4(x0.x, x1.x, x0.y, x1.y);
@@ -2062,6 +2062,8 @@ __global__ void __launch_bounds__(1024, 4) das_pair2_kernel(BF_TABLE_PARAMS, KAr
         }
     };
     auto stage = [&](int h, const Staged2& st, bool wipe) {
+        int lane = lane_;                                       // (opaque copy: the per-lane addresses are recomputed here, not hoisted)
+        asm volatile("" : "+v"(lane));
         float* slot = lds + ((h & 1) * HC + my_mic) * G::kSlot;
         float4 x0 = st.v0, x1 = st.v1;
         float* rows;                                            // the two rows this wave writes
@@ -2080,10 +2082,10 @@ __global__ void __launch_bounds__(1024, 4) das_pair2_kernel(BF_TABLE_PARAMS, KAr
         }
         const float p0 = dpp_prev(x0.w), p1 = dpp_prev(x1.w);   // the previous lane's last sample (0 in lane 0: the prefix)
         if (both_copies) {
-            write_row(rows, x0, x1, p0, p1, false);
-            write_row(rows + RS, x0, x1, p0, p1, true);
+            write_row(rows, x0, x1, p0, p1, false, lane);
+            write_row(rows + RS, x0, x1, p0, p1, true, lane);
         } else {
-            write_row(rows, x0, x1, p0, p1, part == 1);
+            write_row(rows, x0, x1, p0, p1, part == 1, lane);
         }
         if (wipe) {
             // the zero prefix (56 samples x 2 frames = 28 quads per row): only the parked rows of the power pass overwrite it
@@ -2184,7 +2186,9 @@ __global__ void __launch_bounds__(1024, 4) das_pair2_kernel(BF_TABLE_PARAMS, KAr
             };
             if (__builtin_expect(a.n_is_pow2, 1)) park(std::true_type{}); else park(std::false_type{});
             __syncthreads();
-            const int g = wave * kWave + lane;            // parked row of this lane
+            int lane_o = lane;                            // (opaque: keeps the per-lane row address out of the registers the sweep needs)
+            asm volatile("" : "+v"(lane_o));
+            const int g = wave * kWave + lane_o;          // parked row of this lane
             const int d = g0 + g;
             if (g < kGroup && d < tile_end && (f == 0 || two)) {
                 const float* row = lds + g * kPark;
@@ -2551,7 +2555,9 @@ __global__ void __launch_bounds__(1024, 4) das_hybrid_pair_kernel(BF_TABLE_PARAM
             };
             if (__builtin_expect(a.n_is_pow2, 1)) park(std::true_type{}); else park(std::false_type{});
             __syncthreads();
-            const int g = wave * kWave + lane;            // parked row of this lane
+            int lane_o = lane;                            // (opaque: keeps the per-lane row address out of the registers the sweep needs)
+            asm volatile("" : "+v"(lane_o));
+            const int g = wave * kWave + lane_o;          // parked row of this lane
             const int d = g0 + g;
             if (g < kGroup && d < tile_end && (f == 0 || two)) {
                 const float* row = lds + g * kPark;
