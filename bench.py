@@ -150,6 +150,23 @@ def extras(torch, nat, delays, mics, dev):
         dt = timed(lambda: nat.lib.bf_das_device(algo_id, win190.data_ptr(), M, img190.data_ptr(), Dn, 190, nat.iptr(mics), M, 0, Dn, s0), torch, 5)
         nat.check()
         out[name] = {"frames_per_s": 190 / dt, "ms_per_launch": dt * 1e3}
+    # what a drop-in user of the reference's one-frame API sees (PC/src/api.c:951-958 -> mimo_lerp with HOST pointers: H2D of the
+    # 64 KB block, launch, D2H of the 40 KB map, sync) -- PCIe-inclusive, never the headline value
+    lerp_tab = np.ascontiguousarray(np.float32(delays)).ravel()
+    nat.lib.load_coefficients_lerp(nat.fptr(lerp_tab), lerp_tab.size)
+    nat.check()
+    one = synth.s2_noise(M, N)
+    img1 = np.zeros(Dn, dtype=np.float32)
+    for _ in range(30):
+        nat.lib.mimo_lerp(nat.fptr(one), nat.fptr(img1), nat.iptr(mics), M)
+    nat.check()
+    t0 = time.perf_counter()
+    for _ in range(300):
+        nat.lib.mimo_lerp(nat.fptr(one), nat.fptr(img1), nat.iptr(mics), M)
+    dt = (time.perf_counter() - t0) / 300
+    nat.check()
+    out["host_pointer_mimo_lerp"] = {"calls_per_s": 1.0 / dt, "us_per_call": dt * 1e6, "note": "one frame per call, host pointers, PCIe both ways, timed inside this process (torch loaded, other streams alive); "
+                                                                                                    "scripts/host_path_latency.py measures the same call at 58 us standalone; real time needs 190.7 windows/s"}
     # config 4
     pipe = FusedPipeline("lerp", 640, dev)
     pipe.load_tables(delays, mics)
@@ -157,10 +174,10 @@ def extras(torch, nat, delays, mics, dev):
     win = torch.from_numpy(synth.frame_batch(M, N, Bf)).to(dev)
     cam = torch.randint(0, 256, (Bf, 640, 640, 3), dtype=torch.uint8, device=dev)
     dt = timed(lambda: pipe.step(win, cam), torch, 10)
-    out["fused_heatmap_overlay_yolo"] = {"frames_per_s": Bf / dt, "batch": Bf, "image": "640x640x3 uint8", "detector": "YOLOv5s-shaped, fp16, random init, 1 class"}
+    out["fused_heatmap_overlay_yolo"] = {"frames_per_s": Bf / dt, "batch": Bf, "image": "640x640x3 uint8", "detector": "YOLOv5s-shaped, fp16 (ultralytics' default predict is fp32), random init, 1 class"}
     x = pipe.detector.preprocess(cam)
     dt = timed(lambda: pipe.detector.postprocess(pipe.detector.raw(x)), torch, 10)
-    out["yolo_only"] = {"detections_per_s": Bf / dt, "batch": Bf, "gflop_per_frame": 15.8}
+    out["yolo_only"] = {"detections_per_s": Bf / dt, "batch": Bf, "gflop_per_frame": 15.8, "dtype": "fp16"}
     # config 3 + frequency-domain DAS: same 64-mic array and 101x101 grid through the frequency-domain geometry
     old = (C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y)
     C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y = 64, 1, 101, 101

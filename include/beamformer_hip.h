@@ -158,8 +158,10 @@ int bf_get_steer(int *n_out);
  *             written to d_images[f*image_stride + d - dir_begin]
  * adaptive_array / n : HOST array of the active mic rows, as in the reference calls
  * [dir_begin, dir_end) : shard of the flat direction grid 0..MAX_RES_X*MAX_RES_Y handled by this call
- * stream    : hipStream_t (0 = null stream).  Enqueue only: no host synchronisation, graph-capturable once
- *             the adaptive array has been uploaded by a first call.
+ * stream    : hipStream_t (0 = null stream).  Enqueue only, graph-capturable -- except the FIRST call for a (table, launch
+ *             geometry) pair, which builds that geometry's digest of the table and waits for it, and a call with a new
+ *             adaptive array, which synchronises the device before replacing the uploaded copy.  Up to four geometries per
+ *             table stay cached (one-frame and batched calls, direction shards), so alternating callers do not rebuild.
  * Returns 0 or -1. */
 int bf_das_device(int algo, const float *d_signals, int m_total, float *d_images, int image_stride, int frames,
                   const int *adaptive_array, int n, int dir_begin, int dir_end, void *stream);

@@ -82,10 +82,26 @@ struct TableSet {
     DevBuf<int32_t> whole;
     DevBuf<float> frac;
     DevBuf<float> taps;
-    DevBuf<int32_t> digest;   // shifted-copies layout: LDS offsets per (direction, mic), see bf::launch_digest
-    DigestKey digest_key;     // what the digest was built for
-    bool digest_direct = false; // ... in the [D][M] layout of the direction-outer kernel variant (table without structure)
-    void drop() { loaded = false; entries = 0; max_whole = 0; digest_key = DigestKey{}; whole.release(); frac.release(); taps.release(); digest.release(); }
+    // Digests of this table (shifted-copies layouts: LDS offsets per (direction, mic), see bf::launch_digest), one per launch
+    // geometry that has been used -- one-frame and batched calls, the direction shards of several ranks -- so that alternating
+    // callers do not rebuild (and re-synchronise) on every call, and a digest that an earlier launch on another stream may still
+    // be reading is never overwritten in place: a slot is reused only after a device-wide synchronisation.
+    struct DigestSlot {
+        DevBuf<int32_t> buf;
+        DigestKey key;            // what the digest was built for
+        bool direct = false;      // ... in the [D][M] layout of the direction-outer kernel variant (table without structure)
+        unsigned long long used = 0;
+    };
+    static constexpr int kDigestSlots = 4;
+    DigestSlot digests[kDigestSlots];
+    unsigned long long digest_clock = 0;
+    void invalidate_digests() { for (auto& d : digests) d.key = DigestKey{}; }   // (buffers stay allocated; keys never match again)
+    void drop()
+    {
+        loaded = false; entries = 0; max_whole = 0;
+        whole.release(); frac.release(); taps.release();
+        for (auto& d : digests) { d.buf.release(); d.key = DigestKey{}; d.direct = false; d.used = 0; }
+    }
 };
 
 enum Slot { SLOT_PAD = 0, SLOT_LERP, SLOT_FIR, SLOT_HYBRID, SLOT_TRUNC, SLOT_COUNT };
@@ -255,6 +271,8 @@ bool upload_mics(const int* adaptive, int n, int* max_row)
     }
     *max_row = mx;
     if ((int)s.mics_host.size() == n && std::equal(adaptive, adaptive + n, s.mics_host.begin()) && s.d_mics.p) return true;
+    // a new adaptive array: launches already enqueued on the caller's (non-blocking) streams may still read the old copy
+    if (s.d_mics.p && !HIP_OK(hipDeviceSynchronize())) return false;
     if (!upload(s.d_mics, adaptive, (size_t)n)) return false;
     s.mics_host.assign(adaptive, adaptive + n);
     return true;
@@ -316,18 +334,30 @@ bool plan_or_error(bf::DasLaunch& L, bf::DasPlan* plan)
 bool ensure_digest(TableSet& t, bf::DasLaunch& L, bf::DasPlan& plan, hipStream_t stream)
 {
     S().last_variant = plan.layout == 2 ? (plan.nf == 2 ? 7 : 4) : plan.layout;   // refined below for the digest-driven kernels
-    if (plan.layout != 2 || L.algo == bf::ALGO_FIR_NAIVE || L.algo == bf::ALGO_FIR_VEC) return true;   // the plain FIRs have no whole-sample table
+    const bool plain_fir = L.algo == bf::ALGO_FIR_NAIVE || L.algo == bf::ALGO_FIR_VEC;
+    if (plan.layout != 2 || (plain_fir && plan.nf != 2)) return true;   // the plain FIRs have no whole-sample table (their pair kernel wants the taps regrouped)
     // everything the digest depends on: the plan's geometry, the algorithm and (grouped layouts) the direction range
     const DigestKey key{true, plan.mic_chunk, plan.row_stride, plan.lead, L.algo, plan.dpw, L.dir_begin, L.dir_end, L.n_mics, plan.nf};
-    if (!(t.digest_key == key) || !t.digest.p) {
+    TableSet::DigestSlot* slot = nullptr;
+    for (auto& d : t.digests)
+        if (d.buf.p && d.key == key) slot = &d;
+    if (slot == nullptr) {
         State& s = S();
-        if (!HIP_OK(t.digest.reserve(bf::digest_elements(L, plan))) || !HIP_OK(s.d_counter.reserve(1))) return false;
-        t.digest_direct = false;
+        // an unused slot, else the least recently used one -- which launches still in flight on other streams may be reading
+        TableSet::DigestSlot* victim = &t.digests[0];
+        for (auto& d : t.digests) {
+            if (!d.buf.p || !d.key.valid) { victim = &d; break; }
+            if (d.used < victim->used) victim = &d;
+        }
+        if (victim->buf.p && !HIP_OK(hipDeviceSynchronize())) return false;
+        victim->key = DigestKey{};
+        if (!HIP_OK(victim->buf.reserve(bf::digest_elements(L, plan))) || !HIP_OK(s.d_counter.reserve(1))) return false;
+        victim->direct = false;
         const bool plain = L.algo == bf::ALGO_PAD || L.algo == bf::ALGO_LERP;
-        const bool grouped = plain || (L.algo == bf::ALGO_HYBRID && plan.nf == 2);
+        const bool grouped = plain || ((L.algo == bf::ALGO_HYBRID || plain_fir) && plan.nf == 2);
         if (grouped && !HIP_OK(hipMemsetAsync(s.d_counter.p, 0, sizeof(unsigned long long), stream))) return false;
-        if (!HIP_OK(bf::launch_digest(L, plan, t.digest.p, grouped ? s.d_counter.p : nullptr, false, stream))) return false;
-        // once per (table, layout): wait, so that a later launch on ANOTHER stream cannot overtake the digest's construction
+        if (!HIP_OK(bf::launch_digest(L, plan, victim->buf.p, grouped ? s.d_counter.p : nullptr, false, stream))) return false;
+        // once per (table, geometry): wait, so that a later launch on ANOTHER stream cannot overtake the digest's construction
         if (!HIP_OK(hipStreamSynchronize(stream))) return false;
         if (plain && plan.waves == 16) {
             // A table without structure (more than half of the direction steps change the delay) defeats the sweep: use the
@@ -338,18 +368,20 @@ bool ensure_digest(TableSet& t, bf::DasLaunch& L, bf::DasPlan& plan, hipStream_t
             if (steps > 0 && 2 * (long long)reloads > steps) {
                 L.tab.digest_direct = true;
                 if (!plan_or_error(L, &plan)) return false;     // that variant reads at every step: four shifted copies, its own chunk size
-                if (!HIP_OK(bf::launch_digest(L, plan, t.digest.p, nullptr, true, stream)) || !HIP_OK(hipStreamSynchronize(stream))) return false;
-                t.digest_direct = true;
+                if (!HIP_OK(bf::launch_digest(L, plan, victim->buf.p, nullptr, true, stream)) || !HIP_OK(hipStreamSynchronize(stream))) return false;
+                victim->direct = true;
             }
         }
-        t.digest_key = key;                                     // (the key is the sweep plan's: what the caller's planning yields next time)
-    } else if (t.digest_direct) {
+        victim->key = key;                                      // (the key is the sweep plan's: what the caller's planning yields next time)
+        slot = victim;
+    } else if (slot->direct) {
         L.tab.digest_direct = true;
         if (!plan_or_error(L, &plan)) return false;
     }
-    L.tab.digest_direct = t.digest_direct;
-    L.tab.digest = t.digest.p;
-    S().last_variant = (L.algo == bf::ALGO_PAD || L.algo == bf::ALGO_LERP) ? (t.digest_direct ? 3 : plan.nf == 2 ? (plan.interleaved ? 8 : 5) : plan.long_rows ? 6 : 2) : plan.nf == 2 ? 7 : 4;
+    slot->used = ++t.digest_clock;
+    L.tab.digest_direct = slot->direct;
+    L.tab.digest = slot->buf.p;
+    S().last_variant = (L.algo == bf::ALGO_PAD || L.algo == bf::ALGO_LERP) ? (slot->direct ? 3 : plan.nf == 2 ? (plan.interleaved ? 8 : 5) : plan.long_rows ? 6 : 2) : plan.nf == 2 ? 7 : 4;
     return true;
 }
 
@@ -494,7 +526,7 @@ bool load_whole_only(int slot, const int* whole, int n, const char* who)
     if (!sanitize_whole(w, s.sz.n_samples, &mx, who)) return false;
     if (!upload(t.whole, w.data(), w.size())) return false;
     t.loaded = true; t.entries = n; t.max_whole = mx;
-    t.digest_key = DigestKey{};   // new table values: any digest built from the old ones is stale
+    t.invalidate_digests();   // new table values: any digest built from the old ones is stale
     return true;
 }
 
@@ -655,7 +687,7 @@ void load_coefficients_lerp(float* delays, int n)
     if (!sanitize_whole(w, s.sz.n_samples, &mx, "load_coefficients_lerp")) return;
     if (!upload(t.whole, w.data(), w.size()) || !upload(t.frac, h.data(), h.size())) return;
     t.loaded = true; t.entries = n; t.max_whole = mx;
-    t.digest_key = DigestKey{};   // new table values: any digest built from the old ones is stale
+    t.invalidate_digests();   // new table values: any digest built from the old ones is stale
 }
 void unload_coefficients_lerp(void) { std::lock_guard<std::mutex> lock(S().mu); S().tab[SLOT_LERP].drop(); }
 
@@ -689,7 +721,7 @@ void load_coefficients_convolve(float* h, int n)
     TableSet& t = s.tab[SLOT_FIR];
     if (!upload(t.taps, h, (size_t)n)) return;
     t.loaded = true; t.entries = n; t.max_whole = 0;
-    t.digest_key = DigestKey{};
+    t.invalidate_digests();   // new table values: any digest built from the old ones is stale
 }
 void unload_coefficients_convolve(void) { std::lock_guard<std::mutex> lock(S().mu); S().tab[SLOT_FIR].drop(); }
 
@@ -736,7 +768,7 @@ void load_coefficients_convolve_hybrid(float* delays, int n)
     if (!sanitize_whole(w, s.sz.n_samples, &mx, "load_coefficients_convolve_hybrid")) return;
     if (!upload(t.whole, w.data(), w.size()) || !upload(t.taps, taps.data(), taps.size())) return;
     t.loaded = true; t.entries = n; t.max_whole = mx;
-    t.digest_key = DigestKey{};   // new table values: any digest built from the old ones is stale
+    t.invalidate_digests();   // new table values: any digest built from the old ones is stale
 }
 void unload_coefficients_convolve_hybrid(void) { std::lock_guard<std::mutex> lock(S().mu); S().tab[SLOT_HYBRID].drop(); }
 

@@ -50,6 +50,7 @@ struct KArgs {
     int n_frames;   // frames of the launch (das_pair_kernel: whether a workgroup's second frame exists)
     int wg_frames, frame_inner;   // workgroup id -> (tile, frame [pair]): see tile_and_frame()
     long long digest_h_off;   // shifted-copies pad / lerp: where the grouped lerp weights start in the digest buffer (floats)
+    long long digest_t_off;   // the 8-tap FIR pair kernel: where the taps regrouped per 8 directions start in the digest buffer (floats)
 };
 
 // Workgroup id -> (direction tile, frame or frame pair).  Ids go round-robin over the 8 XCDs.
@@ -672,7 +673,8 @@ __global__ void __launch_bounds__(256) digest_kernel(const int32_t* __restrict__
 __global__ void __launch_bounds__(256) digest_grouped_kernel(const int32_t* __restrict__ whole, const float* __restrict__ frac, int32_t* __restrict__ digest,
                                                              long long entries, long long h_off, int n_mics, int gdirs, int dir_begin, int dir_end,
                                                              int mic_chunk, int arrays, int row_stride, int lead, int bias, int ncopies,
-                                                             unsigned long long* __restrict__ reload_count, int pack_guards, int scale)
+                                                             unsigned long long* __restrict__ reload_count, int pack_guards, int scale,
+                                                             const float* __restrict__ taps, long long t_off)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < entries; i += (long long)gridDim.x * blockDim.x) {
         const int j = (int)(i % gdirs);
@@ -681,6 +683,15 @@ __global__ void __launch_bounds__(256) digest_grouped_kernel(const int32_t* __re
         const long long g = gm / n_mics;
         long long d = dir_begin + g * gdirs + j;
         if (d > dir_end - 1) d = dir_end - 1;
+        if (taps != nullptr) {
+            // the 8 taps of (direction, mic), regrouped like the entries: [group][mic][direction of the group][8] -- the FIR sweep
+            // then walks ONE pointer per wave (eight row pointers cost it 14 scalar registers it does not have)
+            const float4* src = reinterpret_cast<const float4*>(taps + ((size_t)d * n_mics + mic) * 8);
+            float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(digest) + t_off + i * 8);
+            dst[0] = src[0];
+            dst[1] = src[1];
+        }
+        if (whole == nullptr) continue;                 // the plain FIRs have no whole-sample table
         const int m = mic % mic_chunk;
         const int pd = whole[d * n_mics + mic] + bias;
         // (scale = 2: rows hold two frames interleaved sample by sample, a sample is two floats wide)
@@ -2386,7 +2397,7 @@ __global__ void __launch_bounds__(1024, 4) das_hybrid_pair_kernel(BF_TABLE_PARAM
     const float* __restrict__ sig1 = signals + (size_t)f1 * a.m_total * N;
     float* __restrict__ img0 = images + (size_t)f0 * a.image_stride;
     float* __restrict__ img1 = images + (size_t)f1 * a.image_stride;
-    const int32_t* __restrict__ dig = reinterpret_cast<const int32_t*>(frac);   // the digest rides in the `frac` slot (hybrid has no weights)
+    const int32_t* __restrict__ dig = reinterpret_cast<const int32_t*>(frac);   // the digest (offsets, guards, regrouped taps) rides in the `frac` slot
 
     // staging: wave w stages mic w of every half, both frames.  Lane c holds half c's mic id (first 64 halves).
     const int vmic = (lane < n_half) ? mics[lane * HC + wave] : 0;
@@ -2456,10 +2467,9 @@ __global__ void __launch_bounds__(1024, 4) das_hybrid_pair_kernel(BF_TABLE_PARAM
                 const int m0 = h * HC;
                 const int32_t* __restrict__ et = dig + (kHybrid ? (grp * M + m0) * DW : 0);       // LDS offsets, 8 per mic (hybrid only)
                 const int32_t* __restrict__ nt = dig + (kHybrid ? a.digest_h_off + (grp * M + m0) * DW : 0);   // packed guards, 8 per mic
-                // taps [D][M][8]: one row pointer per direction of the wave (directions past the end repeat the last one)
-                const unsigned long long* __restrict__ tp[DW];
-#pragma unroll
-                for (int j = 0; j < DW; ++j) tp[j] = reinterpret_cast<const unsigned long long*>(taps + ((size_t)min(dw0 + j, a.dir_end - 1) * M + m0) * 8);
+                // taps regrouped by digest_grouped_kernel: [group of 8 directions][mic][direction][8] -- one pointer per wave
+                const unsigned long long* __restrict__ tg =
+                    reinterpret_cast<const unsigned long long*>(reinterpret_cast<const float*>(dig) + a.digest_t_off + (grp * M + m0) * DW * 8);
                 struct Entries { int e[DW]; int n[DW]; };
                 struct Taps { unsigned long long h[4]; };
                 auto request = [&](Entries& t, int m) {
@@ -2469,7 +2479,7 @@ __global__ void __launch_bounds__(1024, 4) das_hybrid_pair_kernel(BF_TABLE_PARAM
                 auto request_taps = [&](Taps& t, auto jc, int m) {
                     constexpr int j = decltype(jc)::value;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) t.h[k] = tp[j][m * 4 + k];
+                    for (int k = 0; k < 4; ++k) t.h[k] = tg[(m * DW + j) * 4 + k];
                 };
                 Entries E[2];
                 Taps T[3];
@@ -2523,8 +2533,7 @@ __global__ void __launch_bounds__(1024, 4) das_hybrid_pair_kernel(BF_TABLE_PARAM
                 for (int t = 0; t < 2; ++t) {                   // 6 mics per trip: entry sets alternate, taps sets repeat after 3 mics
                     mic(0, I0{}, I0{}); mic(1, I1{}, I2{}); mic(2, I0{}, I1{}); mic(3, I1{}, I0{}); mic(4, I0{}, I2{}); mic(5, I1{}, I1{});
                     et += 6 * DW; nt += 6 * DW; m0s += 6;
-#pragma unroll
-                    for (int j = 0; j < DW; ++j) tp[j] += 6 * 4;
+                    tg += 6 * DW * 4;
                 }
                 mic(0, I0{}, I0{}); mic(1, I1{}, I2{}); mic(2, I0{}, I1{}); mic(3, I1{}, I0{});
                 __builtin_amdgcn_s_waitcnt(0xC07F);             // the requests made past the half's end have landed (and are dropped)
@@ -2882,7 +2891,7 @@ hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, in
             if constexpr (kFir) {
                 if (plan.nf == 2) {                             // das_hybrid_pair_kernel<hybrid | fir_naive | fir_vec>
                     using HG = copies::HybridGeo;
-                    if ((ALGO == ALGO_HYBRID && L.tab.digest == nullptr) || plan.waves != copies::kWaves || plan.mic_chunk != HG::kMc || plan.row_stride != HG::kRs ||
+                    if (L.tab.digest == nullptr || plan.waves != copies::kWaves || plan.mic_chunk != HG::kMc || plan.row_stride != HG::kRs ||
                         plan.lead != HG::kLead || (L.n_mics % 16) != 0 || L.n_taps != 8)
                         return hipErrorInvalidValue;
                     auto kernel = copies::das_hybrid_pair_kernel<ALGO>;
@@ -2890,7 +2899,7 @@ hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, in
                     if (e != hipSuccess) return e;
                     const dim3 pair_grid((unsigned)plan.n_tiles * (unsigned)((frames + 1) / 2));
                     hipLaunchKernelGGL(kernel, pair_grid, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole,
-                                       ALGO == ALGO_HYBRID ? reinterpret_cast<const float*>(L.tab.digest) : L.tab.frac, L.tab.taps, a);
+                                       reinterpret_cast<const float*>(L.tab.digest), L.tab.taps, a);
                     return hipGetLastError();
                 }
             }
@@ -3020,6 +3029,7 @@ KArgs make_args(const DasLaunch& L, const DasPlan& plan)
     a.wg_frames = plan.nf == 2 ? (L.frames + 1) / 2 : L.frames;
     a.frame_inner = plan.frame_inner;
     a.digest_h_off = (plan.layout == 2 && (L.algo == ALGO_LERP || (L.algo == ALGO_HYBRID && plan.nf == 2))) ? grouped_entries_for_args(L, plan) : 0;
+    a.digest_t_off = (plan.layout == 2 && L.algo == ALGO_HYBRID && plan.nf == 2) ? 2 * grouped_entries_for_args(L, plan) : 0;
     return a;
 }
 
@@ -3212,7 +3222,9 @@ size_t digest_elements(const DasLaunch& L, const DasPlan& plan)
     const size_t direct = (size_t)L.n_dirs * (size_t)L.n_mics;                 // the [D][M] layout of the DIRECT variant
     if (L.algo == ALGO_PAD) return std::max((size_t)grouped_entries(L, plan), direct);
     if (L.algo == ALGO_LERP) return std::max((size_t)(2 * grouped_entries(L, plan)), direct);    // offsets, then the lerp weights in the same order
-    if (L.algo == ALGO_HYBRID) return std::max((size_t)L.n_dirs * (size_t)L.n_mics, plan.nf == 2 ? (size_t)(2 * grouped_entries(L, plan)) : (size_t)0);   // pair kernel: offsets, then the packed guards
+    // the FIR pair kernel: offsets and packed guards (hybrid), then the taps regrouped per 8 directions
+    if (L.algo == ALGO_HYBRID) return std::max((size_t)L.n_dirs * (size_t)L.n_mics, plan.nf == 2 ? (size_t)(10 * grouped_entries(L, plan)) : (size_t)0);
+    if ((L.algo == ALGO_FIR_NAIVE || L.algo == ALGO_FIR_VEC) && plan.nf == 2) return (size_t)(8 * grouped_entries(L, plan));
     return 0;
 }
 
@@ -3223,14 +3235,17 @@ hipError_t launch_digest(const DasLaunch& L, const DasPlan& plan, int32_t* d_dig
     // (`arrays`: rows of one staged mic in units of its shifted copies -- samples, lerp's differences, and both frames of the pair kernel)
     // (the hybrid pair kernel interleaves its two frames inside a row: one array per mic)
     const int arrays = ((L.algo == ALGO_LERP) ? 2 : 1) * ((plan.nf == 2 && !plan.interleaved) ? 2 : 1), bias = (L.algo == ALGO_LERP) ? 1 : (L.algo == ALGO_HYBRID) ? 5 : 0;
+    const bool fir_pair = plan.nf == 2 && (L.algo == ALGO_HYBRID || L.algo == ALGO_FIR_NAIVE || L.algo == ALGO_FIR_VEC);
     if ((L.algo == ALGO_HYBRID && plan.nf != 2) || direct) {
         hipLaunchKernelGGL(digest_kernel, dim3(1024), dim3(256), 0, stream, L.tab.whole, d_digest, (long long)L.n_dirs * L.n_mics, L.n_mics, plan.mic_chunk,
                            arrays, plan.row_stride, plan.lead, bias, plan.copies);
     } else {
         const long long entries = grouped_entries(L, plan);
-        hipLaunchKernelGGL(digest_grouped_kernel, dim3(1024), dim3(256), 0, stream, L.tab.whole, L.algo == ALGO_LERP ? L.tab.frac : nullptr, d_digest,
+        hipLaunchKernelGGL(digest_grouped_kernel, dim3(1024), dim3(256), 0, stream, L.algo == ALGO_HYBRID || !fir_pair ? L.tab.whole : nullptr,
+                           L.algo == ALGO_LERP ? L.tab.frac : nullptr, d_digest,
                            entries, entries, L.n_mics, plan.dpw, L.dir_begin, L.dir_end, plan.mic_chunk, arrays, plan.row_stride, plan.lead, bias,
-                           plan.copies, d_reload_count, L.algo == ALGO_HYBRID ? 1 : 0, plan.interleaved ? 2 : 1);
+                           plan.copies, d_reload_count, L.algo == ALGO_HYBRID ? 1 : 0, plan.interleaved ? 2 : 1, fir_pair ? L.tab.taps : nullptr,
+                           fir_pair ? (L.algo == ALGO_HYBRID ? 2 * entries : 0) : 0);
     }
     return hipGetLastError();
 }
