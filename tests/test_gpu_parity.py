@@ -290,6 +290,11 @@ def _torch():
     return torch
 
 
+def batch_variant(algo, frames):
+    """bf_last_das_variant() of a batch on geometric tables at N <= 256, M % 16 == 0 (include/beamformer_hip.h)"""
+    return 8 if algo == "lerp" else 5
+
+
 @pytest.mark.parametrize("algo", ["pad", "lerp"])
 def test_batched_device_path(nat, algo):
     """bf_das_device on HBM-resident frames: every frame equals the host-pointer call; direction shards equal slices."""
@@ -308,7 +313,7 @@ def test_batched_device_path(nat, algo):
     assert nat.lib.bf_das_device(ALGOS[algo], d_sig.data_ptr(), M, d_img.data_ptr(), D, F, nat.iptr(mics), M, 0, D, stream) == 0
     torch.cuda.synchronize()
     assert np.array_equal(d_img.cpu().numpy(), ref_imgs)
-    assert nat.lib.bf_last_das_variant() == (8 if algo == "lerp" else 5)   # geometric tables, a batch: the two-frame sweep (lerp: frame-interleaved rows)
+    assert nat.lib.bf_last_das_variant() == batch_variant(algo, F)   # geometric tables, a batch: the two-frame sweep (lerp: frame-interleaved rows)
     # two direction shards, as two ranks would compute them
     cut = 5003
     lo = torch.full((F, cut), float("nan"), dtype=torch.float32, device="cuda")
@@ -319,7 +324,7 @@ def test_batched_device_path(nat, algo):
     assert np.array_equal(torch.cat([lo, hi], dim=1).cpu().numpy(), ref_imgs)
 
 
-@pytest.mark.parametrize("cfg,n_active,F", [("cfg2", 64, 5), ("cfg2", 64, 2), ("cfg2", 32, 3), ("shipped", 256, 3)])
+@pytest.mark.parametrize("cfg,n_active,F", [("cfg2", 64, 5), ("cfg2", 64, 2), ("cfg2", 32, 3), ("shipped", 256, 3), ("cfg2", 64, 4), ("cfg2", 48, 7), ("shipped", 256, 6)])
 @pytest.mark.parametrize("algo", ["pad", "lerp"])
 def test_batched_frame_pairs(nat, oracle_lib, algo, cfg, n_active, F):
     """The two-frames-per-workgroup kernel: odd frame counts (the last workgroup row owns a single frame), a subset of the
@@ -341,7 +346,7 @@ def test_batched_frame_pairs(nat, oracle_lib, algo, cfg, n_active, F):
     assert nat.lib.bf_das_device(ALGOS[algo], d_sig.data_ptr(), M, d_img.data_ptr(), D, F, nat.iptr(mics), n_active, 0, D,
                                  torch.cuda.current_stream().cuda_stream) == 0, nat.check()
     torch.cuda.synchronize()
-    assert nat.lib.bf_last_das_variant() == (8 if algo == "lerp" else 5)
+    assert nat.lib.bf_last_das_variant() == batch_variant(algo, F)
     got = d_img.cpu().numpy()
     assert np.array_equal(got[F - 1], one.reshape(-1))
     for f in range(F):
@@ -413,7 +418,7 @@ def test_batched_frame_pairs_short_block(nat, oracle_lib, algo):
         assert nat.lib.bf_das_device(ALGOS[algo], d_sig.data_ptr(), M, d_img.data_ptr(), D, F, nat.iptr(mics), M, 0, D,
                                      torch.cuda.current_stream().cuda_stream) == 0, nat.check()
         torch.cuda.synchronize()
-        assert nat.lib.bf_last_das_variant() == (8 if algo == "lerp" else 5)
+        assert nat.lib.bf_last_das_variant() == batch_variant(algo, F)
         got = d_img.cpu().numpy()
         for f in range(F):
             assert np.array_equal(got[f], orc.mimo_range(ALGOS[algo], frames[f], mics, 0, D).reshape(-1)), f
