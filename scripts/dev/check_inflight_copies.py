@@ -174,13 +174,15 @@ def scan_kernel(insts, labels):
 
 
 def hardwired_gaps(path):
-    """das_pair2_kernel keeps a mic's quads in hard-wired registers (v96..v120, named as clobbers) from its statement S1 (reads, step 0)
+    """das_pair2_kernel (and das_long_kernel for lerp: v90..v127) keeps a mic's quads in hard-wired registers (v96..v120, named as clobbers) from its statement S1 (reads, step 0)
     to its statement S2 (steps 1..7); the compiler is free to use those registers in between.  -> [(line, instruction)] for every
     instruction between a ';BF_S1_END' and the next ';BF_S2_BEGIN' that names one of v96..v120 (only table requests belong there)."""
-    bad, inside, pairs = [], False, 0
+    bad, inside, pairs, regs = [], False, 0, set(range(96, 121))
     for lineno, line in enumerate(open(path), 1):
         if "BF_S1_END" in line:
             inside = True
+            m = re.search(r"BF_S1_END\s+(\d+)\s+(\d+)", line)      # das_long_kernel names its own range: ';BF_S1_END 90 127'
+            regs = set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set(range(96, 121))
             continue
         if "BF_S2_BEGIN" in line:
             inside, pairs = False, pairs + 1
@@ -190,7 +192,7 @@ def hardwired_gaps(path):
         l = line.split(";")[0].strip()
         if not l or l.startswith(".") or l.endswith(":"):
             continue
-        if all_vregs(l) & set(range(96, 121)):           # (other vector work, e.g. a compare on loop state, is harmless)
+        if all_vregs(l) & regs:           # (other vector work, e.g. a compare on loop state, is harmless)
             bad.append((lineno, l))
     return pairs, bad
 

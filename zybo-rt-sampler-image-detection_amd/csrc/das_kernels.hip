@@ -801,6 +801,7 @@ __device__ __forceinline__ void write_copies(float* row0, int rs, int col, int l
 
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // The quad (two register pairs) of one 256-sample segment of a staged mic row, and of its difference row for lerp.
 struct Quad { f32x2 lo, hi; };
@@ -821,6 +822,8 @@ struct Quad { f32x2 lo, hi; };
 #define BF_RELOAD_TAIL "s_waitcnt lgkmcnt(0)\n\ts_branch .Lback_%=\n\t.subsection 0"
 #define BF_S_OPS(sg) [s##sg##l] "+v"(S[sg].lo), [s##sg##h] "+v"(S[sg].hi)
 #define BF_D_OPS(sg) [d##sg##l] "+v"(D[sg].lo), [d##sg##h] "+v"(D[sg].hi)
+#define BF_S_OUT(sg) [s##sg##l] "=&v"(S[sg].lo), [s##sg##h] "=&v"(S[sg].hi)
+#define BF_D_OUT(sg) [d##sg##l] "=&v"(D[sg].lo), [d##sg##h] "=&v"(D[sg].hi)
 
 template <int NSEG, bool LERP>
 __device__ __forceinline__ void reload_quads(Quad (&S)[NSEG], Quad (&D)[NSEG], int e, int ep, int lbase, int d_off)
@@ -938,25 +941,26 @@ __device__ __forceinline__ void reload_quads_cf(Quad (&S)[NSEG], Quad (&D)[NSEG]
                      : [e] "s"(e), [ep] "s"(ep), [lb] "v"(lbase), [doff] "s"(d_off) : "scc");
     }
 }
-// (issue and wait in ONE statement: a mic's first quads, read in place)
+// (issue and wait in ONE statement: a mic's first quads, read in place; pure outputs -- as in-out operands the compiler has to give
+// them a defined value first: 16 v_mov per mic in the 4-segment lerp sweep, a fifth of its vector instructions)
 template <int NSEG, bool LERP>
 __device__ __forceinline__ void load_quads_cf(Quad (&S)[NSEG], Quad (&D)[NSEG], int e, int lbase, int d_off)
 {
     int ad, ad2;
     if constexpr (NSEG == 2 && !LERP) {
         asm volatile("v_add_u32 %[ad], %[e], %[lb]\n\t" BF_RD(0, 0, 512) BF_RD(1, 1024, 1536) "s_waitcnt lgkmcnt(0)"
-                     : BF_S_OPS(0), BF_S_OPS(1), [ad] "=&v"(ad) : [e] "s"(e), [lb] "v"(lbase));
+                     : BF_S_OUT(0), BF_S_OUT(1), [ad] "=&v"(ad) : [e] "s"(e), [lb] "v"(lbase));
     } else if constexpr (NSEG == 2 && LERP) {
         asm volatile("v_add_u32 %[ad], %[e], %[lb]\n\tv_add_u32 %[ad2], %[ad], %[doff]\n\t" BF_RD(0, 0, 512) BF_RDD(0, 0, 512) BF_RD(1, 1024, 1536)
                          BF_RDD(1, 1024, 1536) "s_waitcnt lgkmcnt(0)"
-                     : BF_S_OPS(0), BF_D_OPS(0), BF_S_OPS(1), BF_D_OPS(1), [ad] "=&v"(ad), [ad2] "=&v"(ad2) : [e] "s"(e), [lb] "v"(lbase), [doff] "s"(d_off));
+                     : BF_S_OUT(0), BF_D_OUT(0), BF_S_OUT(1), BF_D_OUT(1), [ad] "=&v"(ad), [ad2] "=&v"(ad2) : [e] "s"(e), [lb] "v"(lbase), [doff] "s"(d_off));
     } else if constexpr (NSEG == 4 && !LERP) {
         asm volatile("v_add_u32 %[ad], %[e], %[lb]\n\t" BF_RD(0, 0, 512) BF_RD(1, 1024, 1536) BF_RD(2, 2048, 2560) BF_RD(3, 3072, 3584) "s_waitcnt lgkmcnt(0)"
-                     : BF_S_OPS(0), BF_S_OPS(1), BF_S_OPS(2), BF_S_OPS(3), [ad] "=&v"(ad) : [e] "s"(e), [lb] "v"(lbase));
+                     : BF_S_OUT(0), BF_S_OUT(1), BF_S_OUT(2), BF_S_OUT(3), [ad] "=&v"(ad) : [e] "s"(e), [lb] "v"(lbase));
     } else {
         asm volatile("v_add_u32 %[ad], %[e], %[lb]\n\tv_add_u32 %[ad2], %[ad], %[doff]\n\t" BF_RD(0, 0, 512) BF_RDD(0, 0, 512) BF_RD(1, 1024, 1536)
                          BF_RDD(1, 1024, 1536) BF_RD(2, 2048, 2560) BF_RDD(2, 2048, 2560) BF_RD(3, 3072, 3584) BF_RDD(3, 3072, 3584) "s_waitcnt lgkmcnt(0)"
-                     : BF_S_OPS(0), BF_D_OPS(0), BF_S_OPS(1), BF_D_OPS(1), BF_S_OPS(2), BF_D_OPS(2), BF_S_OPS(3), BF_D_OPS(3), [ad] "=&v"(ad), [ad2] "=&v"(ad2)
+                     : BF_S_OUT(0), BF_D_OUT(0), BF_S_OUT(1), BF_D_OUT(1), BF_S_OUT(2), BF_D_OUT(2), BF_S_OUT(3), BF_D_OUT(3), [ad] "=&v"(ad), [ad2] "=&v"(ad2)
                      : [e] "s"(e), [lb] "v"(lbase), [doff] "s"(d_off));
     }
 }
@@ -966,6 +970,8 @@ __device__ __forceinline__ void load_quads_cf(Quad (&S)[NSEG], Quad (&D)[NSEG], 
 #undef BF_RDD
 #undef BF_S_OPS
 #undef BF_D_OPS
+#undef BF_S_OUT
+#undef BF_D_OUT
 
 // acc += quad (pad) / acc += fma(h, D, S) (lerp) on the two register pairs of a segment.  asm so that it stays between
 // the reloads in program order (a C++ expression may be sunk below the next reload at the price of register copies).
@@ -1955,6 +1961,19 @@ struct Pair2Geo {
     "v_pk_fma_f32 v[116:117], %[" #h "], v[108:109], v[100:101] " mods "\n\tv_pk_fma_f32 v[118:119], %[" #h "], v[110:111], v[102:103] " mods "\n\t" \
     "v_pk_add_f32 %[a" #n "0], %[a" #n "0], v[112:113]\n\tv_pk_add_f32 %[a" #n "1], %[a" #n "1], v[114:115]\n\t" \
     "v_pk_add_f32 %[a" #n "2], %[a" #n "2], v[116:117]\n\tv_pk_add_f32 %[a" #n "3], %[a" #n "3], v[118:119]\n\t"
+// A mic's first reads with direction step 0 behind them, each half of the step waiting only for its own reads (LDS returns in order;
+// a counted wait bounds the outstanding operations of any kind, hence the outstanding reads).
+#define BF_I_FIRST_PAD                                                                              \
+    "ds_read_b128 v[96:99], v120\n\tds_read_b128 v[100:103], v120 offset:1024\n\ts_waitcnt lgkmcnt(1)\n\t"  \
+    "v_pk_add_f32 %[a00], %[a00], v[96:97]\n\tv_pk_add_f32 %[a01], %[a01], v[98:99]\n\ts_waitcnt lgkmcnt(0)\n\t" \
+    "v_pk_add_f32 %[a02], %[a02], v[100:101]\n\tv_pk_add_f32 %[a03], %[a03], v[102:103]\n\t"
+#define BF_I_FIRST_LERP(h, mods)                                                                    \
+    "ds_read_b128 v[96:99], v120\n\tds_read_b128 v[104:107], v120 offset:%[g0]\n\t"                \
+    "ds_read_b128 v[100:103], v120 offset:1024\n\tds_read_b128 v[108:111], v120 offset:%[g1]\n\ts_waitcnt lgkmcnt(2)\n\t" \
+    "v_pk_fma_f32 v[112:113], %[" #h "], v[104:105], v[96:97] " mods "\n\tv_pk_fma_f32 v[114:115], %[" #h "], v[106:107], v[98:99] " mods "\n\t" \
+    "v_pk_add_f32 %[a00], %[a00], v[112:113]\n\tv_pk_add_f32 %[a01], %[a01], v[114:115]\n\ts_waitcnt lgkmcnt(0)\n\t" \
+    "v_pk_fma_f32 v[116:117], %[" #h "], v[108:109], v[100:101] " mods "\n\tv_pk_fma_f32 v[118:119], %[" #h "], v[110:111], v[102:103] " mods "\n\t" \
+    "v_pk_add_f32 %[a02], %[a02], v[116:117]\n\tv_pk_add_f32 %[a03], %[a03], v[118:119]\n\t"
 #define BF_I_EVEN "op_sel_hi:[0,1,1]"
 #define BF_I_ODD "op_sel:[1,0,0] op_sel_hi:[1,1,1]"
 #define BF_I_CHECK(n, ep, ec) "s_cmp_lg_u32 %[" #ec "], %[" #ep "]\n\ts_cbranch_scc1 .Lr" #n "_%=\n.Lb" #n "_%=:\n\t"
@@ -1969,11 +1988,11 @@ __device__ __forceinline__ void pair2_first(f32x2 (&acc)[8][4], int e0, unsigned
     using G = Pair2Geo<ALGO>;
     if constexpr (ALGO == ALGO_PAD) {
         // pad_and_sum.c:41-47   out[k] += s[k - p]
-        asm volatile("v_add_u32 v120, %[e0], %[lb]\n\t" BF_I_READ_PAD BF_I_PAD_STEP(0) ";BF_S1_END"
+        asm volatile("v_add_u32 v120, %[e0], %[lb]\n\t" BF_I_FIRST_PAD ";BF_S1_END"
                      : BF_I_ACC(0, 0) : [e0] "s"(e0), [lb] "v"(lbase) : BF_I_CLOB);
     } else {
         // lerp_and_sum.c:50-56  out[k] += s[i] + h * (s[i+1] - s[i]),  i = k - p - 1   (gcc contracts it into one fma)
-        asm volatile("v_add_u32 v120, %[e0], %[lb]\n\t" BF_I_READ_LERP BF_I_LERP_STEP(0, h01, BF_I_EVEN) ";BF_S1_END"
+        asm volatile("v_add_u32 v120, %[e0], %[lb]\n\t" BF_I_FIRST_LERP(h01, BF_I_EVEN) ";BF_S1_END"
                      : BF_I_ACC(0, 0) : [e0] "s"(e0), [h01] "s"(h01), [lb] "v"(lbase), [g0] "n"(G::kDoff), [g1] "n"(G::kDoff + 1024) : BF_I_CLOB);
     }
 }
@@ -2011,6 +2030,8 @@ __device__ __forceinline__ void pair2_rest(f32x2 (&acc)[8][4], const int (&e)[8]
 }
 #undef BF_I_ACC
 #undef BF_I_READ_PAD
+#undef BF_I_FIRST_PAD
+#undef BF_I_FIRST_LERP
 #undef BF_I_READ_LERP
 #undef BF_I_PAD_STEP
 #undef BF_I_LERP_STEP
@@ -2237,7 +2258,6 @@ __global__ void __launch_bounds__(1024, 4) das_pair2_kernel(BF_TABLE_PARAMS, KAr
 //   * interleaved rows need only TWO shifted copies for 16-byte-aligned window reads (the window start must fall on an even
 //     sample), so the LDS image holds 32 mics: two halves of 16, staged under the sweep as in das_pair_kernel.
 // Operation order per output is the reference's (taps 0..7 in order, mics in order): bit-identical maps.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct HybridGeo {
     static constexpr int kC = 2, kLead = Geo<1>::kLead, kRs = 2 * Geo<1>::kRsFir;   // floats per row: two frames interleaved
     static constexpr int kHalf = 16, kMc = 2 * kHalf;
@@ -2600,6 +2620,128 @@ __global__ void __launch_bounds__(1024, 4) das_hybrid_pair_kernel(BF_TABLE_PARAM
 //   * nothing is in flight across statements the compiler cannot see (a mic's first quads are read in place), and the kernel
 //     must not use scratch (tests/test_isa_hazards.py reads the code-object metadata).
 // Mic order and operation order are the reference's; the power is summed in k order from parked rows: bit-identical maps.
+// lerp on long rows: a staged row holds sample PAIRS with their differences, (s[2j], s[2j+1], D[2j], D[2j+1]) per 16 bytes, so that one
+// ds_read_b128 brings both operand pairs of two packed operations (8 LDS instructions per re-read of a 1024-sample row instead of 16;
+// two shifted copies still serve any delay).  The quads live in hard-wired registers -- v[92:123], address v90, products v[124:127] --
+// because a 16-byte read needs a 4-register tuple whose halves the packed operations address, which asm operands cannot express.
+// A mic is two statements: S1 (address, reads, wait, the first direction) and S2 (the other directions with their offset tests and
+// out-of-line re-reads); the compiler's table requests for the mic after next sit between them, and nothing there may name
+// v90..v127 (tests/test_isa_hazards.py).  One statement per group of steps also keeps the hazard recogniser's s_nop out of the sweep.
+#define BF_L_LO "op_sel_hi:[0,1,1]"
+#define BF_L_HI "op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+// lerp_and_sum.c:50-56  out[k] += s[i] + h * (s[i+1] - s[i]),  i = k - p - 1   (gcc contracts it into one fma)
+#define BF_L_SEG(n, sg, h, sel, S0, D0, S1, D1)                                                      \
+    "v_pk_fma_f32 v[124:125], %[" #h "], v[" D0 "], v[" S0 "] " sel "\n\t"                           \
+    "v_pk_fma_f32 v[126:127], %[" #h "], v[" D1 "], v[" S1 "] " sel "\n\t"                           \
+    "v_pk_add_f32 %[a" #n #sg "0], %[a" #n #sg "0], v[124:125]\n\t"                                  \
+    "v_pk_add_f32 %[a" #n #sg "1], %[a" #n #sg "1], v[126:127]\n\t"
+#define BF_L_STEP2(n, h, sel) BF_L_SEG(n, 0, h, sel, "92:93", "94:95", "96:97", "98:99") BF_L_SEG(n, 1, h, sel, "100:101", "102:103", "104:105", "106:107")
+#define BF_L_STEP4(n, h, sel) BF_L_STEP2(n, h, sel) BF_L_SEG(n, 2, h, sel, "108:109", "110:111", "112:113", "114:115") \
+                              BF_L_SEG(n, 3, h, sel, "116:117", "118:119", "120:121", "122:123")
+// (step 0 of a mic: each segment waits only for its own two reads -- LDS returns in order, and a counted wait holds whatever else,
+//  scalar loads included, is still outstanding: at most that many operations of any kind, hence at most that many reads)
+#define BF_L_STEP2_W(n, h, sel) "s_waitcnt lgkmcnt(2)\n\t" BF_L_SEG(n, 0, h, sel, "92:93", "94:95", "96:97", "98:99") \
+                                "s_waitcnt lgkmcnt(0)\n\t" BF_L_SEG(n, 1, h, sel, "100:101", "102:103", "104:105", "106:107")
+#define BF_L_STEP4_W(n, h, sel) "s_waitcnt lgkmcnt(6)\n\t" BF_L_SEG(n, 0, h, sel, "92:93", "94:95", "96:97", "98:99") \
+                                "s_waitcnt lgkmcnt(4)\n\t" BF_L_SEG(n, 1, h, sel, "100:101", "102:103", "104:105", "106:107") \
+                                "s_waitcnt lgkmcnt(2)\n\t" BF_L_SEG(n, 2, h, sel, "108:109", "110:111", "112:113", "114:115") \
+                                "s_waitcnt lgkmcnt(0)\n\t" BF_L_SEG(n, 3, h, sel, "116:117", "118:119", "120:121", "122:123")
+// (the last step of a mic that has a successor in its half: each segment's quads are dead once the step has used them, and the next
+//  mic's reads for that segment are issued right behind -- they fly during the rest of the step and the compiler's code between the mics)
+#define BF_L_RD(q, off) "ds_read_b128 v[" q "], v90 offset:" #off "\n\t"
+#define BF_L_STEP2_PF(n, h, sel) BF_L_SEG(n, 0, h, sel, "92:93", "94:95", "96:97", "98:99") BF_L_RD("92:95", 0) BF_L_RD("96:99", 1024) \
+                                 BF_L_SEG(n, 1, h, sel, "100:101", "102:103", "104:105", "106:107") BF_L_RD("100:103", 2048) BF_L_RD("104:107", 3072)
+#define BF_L_STEP4_PF(n, h, sel) BF_L_STEP2_PF(n, h, sel)                                                                                \
+                                 BF_L_SEG(n, 2, h, sel, "108:109", "110:111", "112:113", "114:115") BF_L_RD("108:111", 4096) BF_L_RD("112:115", 5120) \
+                                 BF_L_SEG(n, 3, h, sel, "116:117", "118:119", "120:121", "122:123") BF_L_RD("116:119", 6144) BF_L_RD("120:123", 7168)
+#define BF_L_READ2 "ds_read_b128 v[92:95], v90\n\tds_read_b128 v[96:99], v90 offset:1024\n\t"          \
+                   "ds_read_b128 v[100:103], v90 offset:2048\n\tds_read_b128 v[104:107], v90 offset:3072\n\t"
+#define BF_L_READ4 BF_L_READ2 "ds_read_b128 v[108:111], v90 offset:4096\n\tds_read_b128 v[112:115], v90 offset:5120\n\t" \
+                   "ds_read_b128 v[116:119], v90 offset:6144\n\tds_read_b128 v[120:123], v90 offset:7168\n\t"
+#define BF_L_ACC2(n, j) [a##n##00] "+v"(acc[j][0][0]), [a##n##01] "+v"(acc[j][0][1]), [a##n##10] "+v"(acc[j][1][0]), [a##n##11] "+v"(acc[j][1][1])
+#define BF_L_ACC4(n, j) BF_L_ACC2(n, j), [a##n##20] "+v"(acc[j][2][0]), [a##n##21] "+v"(acc[j][2][1]), [a##n##30] "+v"(acc[j][3][0]), [a##n##31] "+v"(acc[j][3][1])
+#define BF_L_CHECK(n, ep, ec) "s_cmp_lg_u32 %[" #ec "], %[" #ep "]\n\ts_cbranch_scc1 .Lr" #n "_%=\n.Lb" #n "_%=:\n\t"
+#define BF_L_STUB(n, ec, READ) ".Lr" #n "_%=:\n\tv_add_u32 v90, %[" #ec "], %[lb]\n\t" READ "s_waitcnt lgkmcnt(0)\n\ts_branch .Lb" #n "_%=\n"
+#define BF_L_CLOB "v90", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", \
+                  "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+template <int NSEG>
+__device__ __forceinline__ void long_lerp_first(f32x2 (&acc)[Geo<NSEG>::kDw][NSEG][2], int e0, unsigned long long h0, int lbase)
+{
+    if constexpr (NSEG == 2) {
+        asm volatile("v_add_u32 v90, %[e0], %[lb]\n\t" BF_L_READ2 BF_L_STEP2_W(0, h0, BF_L_LO) ";BF_S1_END 90 127"
+                     : BF_L_ACC2(0, 0) : [e0] "s"(e0), [h0] "s"(h0), [lb] "v"(lbase) : BF_L_CLOB);
+    } else {
+        asm volatile("v_add_u32 v90, %[e0], %[lb]\n\t" BF_L_READ4 BF_L_STEP4_W(0, h0, BF_L_LO) ";BF_S1_END 90 127"
+                     : BF_L_ACC4(0, 0) : [e0] "s"(e0), [h0] "s"(h0), [lb] "v"(lbase) : BF_L_CLOB);
+    }
+}
+// a mic whose reads the previous mic's last step has issued: direction step 0 alone
+template <int NSEG>
+__device__ __forceinline__ void long_lerp_cont(f32x2 (&acc)[Geo<NSEG>::kDw][NSEG][2], unsigned long long h0)
+{
+    if constexpr (NSEG == 2) {
+        asm volatile(";BF_S2_BEGIN\n\t" BF_L_STEP2_W(0, h0, BF_L_LO) ";BF_S1_END 90 127" : BF_L_ACC2(0, 0) : [h0] "s"(h0) : BF_L_CLOB);
+    } else {
+        asm volatile(";BF_S2_BEGIN\n\t" BF_L_STEP4_W(0, h0, BF_L_LO) ";BF_S1_END 90 127" : BF_L_ACC4(0, 0) : [h0] "s"(h0) : BF_L_CLOB);
+    }
+}
+// PF: the mic has a successor in its half, whose first offset is `n0`
+template <int NSEG, bool PF>
+__device__ __forceinline__ void long_lerp_rest(f32x2 (&acc)[Geo<NSEG>::kDw][NSEG][2], const int (&e)[Geo<NSEG>::kDw], const unsigned long long (&h)[Geo<NSEG>::kDw / 2], int lbase,
+                                               int n0)
+{
+#define BF_L_LAST2(n, h) "v_add_u32 v90, %[n0], %[lb]\n\t" BF_L_STEP2_PF(n, h, BF_L_HI) ";BF_S1_END 90 127"
+#define BF_L_LAST4(n, h) "v_add_u32 v90, %[n0], %[lb]\n\t" BF_L_STEP4_PF(n, h, BF_L_HI) ";BF_S1_END 90 127"
+#define BF_L_STUBS2 ".subsection 1\n" BF_L_STUB(1, e1, BF_L_READ2) BF_L_STUB(2, e2, BF_L_READ2) BF_L_STUB(3, e3, BF_L_READ2) BF_L_STUB(4, e4, BF_L_READ2) \
+                    BF_L_STUB(5, e5, BF_L_READ2) BF_L_STUB(6, e6, BF_L_READ2) BF_L_STUB(7, e7, BF_L_READ2) "\t.subsection 0\n\t"
+#define BF_L_STUBS4 ".subsection 1\n" BF_L_STUB(1, e1, BF_L_READ4) BF_L_STUB(2, e2, BF_L_READ4) BF_L_STUB(3, e3, BF_L_READ4) "\t.subsection 0\n\t"
+#define BF_L_BODY2 BF_L_CHECK(1, e0, e1) BF_L_STEP2(1, h0, BF_L_HI) BF_L_CHECK(2, e1, e2) BF_L_STEP2(2, h1, BF_L_LO) BF_L_CHECK(3, e2, e3) BF_L_STEP2(3, h1, BF_L_HI) \
+                   BF_L_CHECK(4, e3, e4) BF_L_STEP2(4, h2, BF_L_LO) BF_L_CHECK(5, e4, e5) BF_L_STEP2(5, h2, BF_L_HI) BF_L_CHECK(6, e5, e6) BF_L_STEP2(6, h3, BF_L_LO) \
+                   BF_L_CHECK(7, e6, e7)
+#define BF_L_BODY4 BF_L_CHECK(1, e0, e1) BF_L_STEP4(1, h0, BF_L_HI) BF_L_CHECK(2, e1, e2) BF_L_STEP4(2, h1, BF_L_LO) BF_L_CHECK(3, e2, e3)
+#define BF_L_IN2 [e0] "s"(e[0]), [e1] "s"(e[1]), [e2] "s"(e[2]), [e3] "s"(e[3]), [e4] "s"(e[4]), [e5] "s"(e[5]), [e6] "s"(e[6]), [e7] "s"(e[7]), \
+                 [h0] "s"(h[0]), [h1] "s"(h[1]), [h2] "s"(h[2]), [h3] "s"(h[3]), [lb] "v"(lbase)
+#define BF_L_IN4 [e0] "s"(e[0]), [e1] "s"(e[1]), [e2] "s"(e[2]), [e3] "s"(e[3]), [h0] "s"(h[0]), [h1] "s"(h[1]), [lb] "v"(lbase)
+#define BF_L_OUT2 BF_L_ACC2(1, 1), BF_L_ACC2(2, 2), BF_L_ACC2(3, 3), BF_L_ACC2(4, 4), BF_L_ACC2(5, 5), BF_L_ACC2(6, 6), BF_L_ACC2(7, 7)
+#define BF_L_OUT4 BF_L_ACC4(1, 1), BF_L_ACC4(2, 2), BF_L_ACC4(3, 3)
+    if constexpr (NSEG == 2 && !PF) {
+        asm volatile(";BF_S2_BEGIN\n\t" BF_L_BODY2 BF_L_STEP2(7, h3, BF_L_HI) BF_L_STUBS2 : BF_L_OUT2 : BF_L_IN2 : "scc", BF_L_CLOB);
+    } else if constexpr (NSEG == 2 && PF) {
+        asm volatile(";BF_S2_BEGIN\n\t" BF_L_BODY2 BF_L_STUBS2 BF_L_LAST2(7, h3) : BF_L_OUT2 : BF_L_IN2, [n0] "s"(n0) : "scc", BF_L_CLOB);
+    } else if constexpr (NSEG == 4 && !PF) {
+        asm volatile(";BF_S2_BEGIN\n\t" BF_L_BODY4 BF_L_STEP4(3, h1, BF_L_HI) BF_L_STUBS4 : BF_L_OUT4 : BF_L_IN4 : "scc", BF_L_CLOB);
+    } else {
+        asm volatile(";BF_S2_BEGIN\n\t" BF_L_BODY4 BF_L_STUBS4 BF_L_LAST4(3, h1) : BF_L_OUT4 : BF_L_IN4, [n0] "s"(n0) : "scc", BF_L_CLOB);
+    }
+#undef BF_L_LAST2
+#undef BF_L_LAST4
+#undef BF_L_STUBS2
+#undef BF_L_STUBS4
+#undef BF_L_BODY2
+#undef BF_L_BODY4
+#undef BF_L_IN2
+#undef BF_L_IN4
+#undef BF_L_OUT2
+#undef BF_L_OUT4
+}
+#undef BF_L_LO
+#undef BF_L_HI
+#undef BF_L_SEG
+#undef BF_L_STEP2
+#undef BF_L_STEP4
+#undef BF_L_STEP2_W
+#undef BF_L_RD
+#undef BF_L_STEP2_PF
+#undef BF_L_STEP4_PF
+#undef BF_L_STEP4_W
+#undef BF_L_READ2
+#undef BF_L_READ4
+#undef BF_L_ACC2
+#undef BF_L_ACC4
+#undef BF_L_CHECK
+#undef BF_L_STUB
+#undef BF_L_CLOB
+
 template <int ALGO, int NSEG>
 struct LongGeo {
     static constexpr bool kLerp = ALGO == ALGO_LERP;
@@ -2622,7 +2764,8 @@ __global__ void __launch_bounds__(1024, 4) das_long_kernel(BF_TABLE_PARAMS, KArg
     const int tile_begin = a.dir_begin + tile * a.tile_dirs;
     if (tile_begin >= a.dir_end) return;
     const int tile_end = min(tile_begin + a.tile_dirs, a.dir_end);
-    const int rs = RS > 0 ? RS : a.row_stride, lead = RS > 0 ? Geo<NSEG>::kLead : a.lead;
+    // rs: samples per staged row (lerp: the plan's row stride counts floats, two per sample -- see `stage`)
+    const int rs = RS > 0 ? RS : (kLerp ? a.row_stride >> 1 : a.row_stride), lead = RS > 0 ? Geo<NSEG>::kLead : a.lead;
     const int M = a.n_mics, N = a.n_samples;                   // M % HC == 0 (plan_das)
     const int n_half = M / HC;
     const float* __restrict__ frame_sig = signals + (size_t)frame * a.m_total * N;
@@ -2631,63 +2774,78 @@ __global__ void __launch_bounds__(1024, 4) das_long_kernel(BF_TABLE_PARAMS, KArg
     const int slot_floats = A * C * rs;                        // floats per staged mic
 
     // This wave stages the pair `wave` of every half: mic (wave / NSEG) of the half, segment (wave % NSEG).
-    const int my_mic = wave / NSEG, my_seg = wave % NSEG;
-    const int vmic = (lane < n_half) ? mics[lane * HC + my_mic] : 0;          // lane c: half c's mic id (first 64 halves)
-    // (`lane` passes through an empty asm in fetch / stage: their per-lane addresses are then recomputed where they are used --
+    // Staging is straight-line code (it runs once per half of HC mics beside 4 HC direction steps per wave, and every instruction --
+    // a taken branch more than ten times over -- costs the SIMD an issue slot like the sweep's own): N % 4 == 0 (plan_das), the
+    // mic id by a scalar load, the two samples DPP cannot reach through one masked load, the prefix wiped at the group's start.
+    const int my_mic = wave / NSEG, my_seg = wave % NSEG, k0 = 256 * my_seg;
+    // (fetch / stage take the lane id from v_mbcnt in a volatile asm: their per-lane addresses are then recomputed where they are used --
     //  a handful of integer operations per half -- instead of being hoisted out of the mic loop into registers the sweep needs)
-    auto fetch = [&](int h) -> Staged {
+    auto lane_id = []() -> int {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
+    // Both loads are unconditional from clamped addresses (a load under a lane mask is merged with zeros -- and waited for -- on the
+    // spot); `stage` zeroes what lies outside the block.
+    int hf = 0, mic_a = mics[my_mic];                           // the half the next fetch reads, and its mic id (wave-uniform: scalar loads)
+    auto fetch_next = [&]() -> Staged {
         Staged st;
-        int lane = lane_;
-        asm volatile("" : "+v"(lane));
-        const int mic = (h < kWave) ? __builtin_amdgcn_readlane(vmic, h) : mics[h * HC + my_mic];
-        const float* src = frame_sig + (size_t)mic * N;
-        const int k = 4 * (64 * my_seg + lane);
-        st.v = make_float4(0.f, 0.f, 0.f, 0.f);
-        st.edge = 0.0f;
-        if ((N & 3) == 0) {
-            if (k < N) st.v = *reinterpret_cast<const float4*>(src + k);
-        } else {
-            if (k < N) st.v.x = src[k];
-            if (k + 1 < N) st.v.y = src[k + 1];
-            if (k + 2 < N) st.v.z = src[k + 2];
-            if (k + 3 < N) st.v.w = src[k + 3];
-        }
-        // what DPP cannot reach: the three samples before the segment and the one after it
-        const int ke = lane < 3 ? 256 * my_seg - 3 + lane : 256 * my_seg + 256;
-        if ((lane < 3 || lane == 63) && ke >= 0 && ke < N) st.edge = src[ke];
+        const int lane = lane_id();
+        const float* src = frame_sig + (size_t)mic_a * N;
+        const int k = min(k0 + 4 * lane, N - 4);
+        st.v = *reinterpret_cast<const float4*>(src + k);
+        // what DPP cannot reach: lane 0 takes the sample before the segment, lane 63 the one after it
+        // (any address for the lanes between; plain arithmetic: a nested conditional becomes two EXEC-masked branches)
+        const int ke = k - (lane == 0 ? 1 : 0) + (lane == 63 ? 4 : 0);
+        st.edge = src[min(max(ke, 0), N - 1)];
+        hf = hf + 1 < n_half ? hf + 1 : 0;
+        mic_a = mics[hf * HC + my_mic];                         // consumed by the next fetch, half a sweep from now
         return st;
     };
-    auto stage = [&](int h, const Staged& st, bool wipe) {
-        int lane = lane_;
-        asm volatile("" : "+v"(lane));
+    auto stage = [&](int h, const Staged& st) {
+        const int lane = lane_id();
         float* row0 = lds + ((h & 1) * HC + my_mic) * slot_floats;
-        const int col = lead + 256 * my_seg;
-        const float4 v = st.v;
-        float py = dpp_prev(v.y), pz = dpp_prev(v.z), pw = dpp_prev(v.w), nx = dpp_next(v.x);
-        const float ey = lane_value(st.edge, 0), ez = lane_value(st.edge, 1), ew = lane_value(st.edge, 2), en = lane_value(st.edge, 63);
-        if (lane == 0) { py = ey; pz = ez; pw = ew; }
-        if (lane == 63) nx = en;
-        write_copies<C>(row0, rs, col, lane, v, py, pz, pw);
+        const int col = lead + k0;
+        const bool in = k0 + 4 * lane < N;
+        const float4 v = make_float4(in ? st.v.x : 0.0f, in ? st.v.y : 0.0f, in ? st.v.z : 0.0f, in ? st.v.w : 0.0f);
+        float pw = dpp_prev(v.w), nx = dpp_next(v.x);          // (0 in lane 0 / lane 63)
+        const float before = my_seg > 0 ? st.edge : 0.0f, after = k0 + 256 < N ? st.edge : 0.0f;
+        pw = lane == 0 ? before : pw;
+        nx = lane == 63 ? after : nx;
         if constexpr (kLerp) {
             // D[i] = s[i+1] - s[i], the reference's own subtraction (lerp_and_sum.c:54); D[-1] stays 0 (prefix)
             const float4 dq = make_float4(v.y - v.x, v.z - v.y, v.w - v.z, nx - v.w);
-            float dy = dpp_prev(dq.y), dz = dpp_prev(dq.z), dw = dpp_prev(dq.w);
-            if (lane == 0 && my_seg > 0) { dy = ez - ey; dz = ew - ez; dw = v.x - ew; }
-            write_copies<C>(row0 + C * rs, rs, col, lane, dq, dy, dz, dw);
+            float dw = dpp_prev(dq.w);
+            if (my_seg > 0) dw = lane == 0 ? v.x - before : dw;
+            // a row of sample pairs with their differences, (s[2j], s[2j+1], D[2j], D[2j+1]): 2 rs floats; copy 1 holds sample i - 1 at position i
+            float4* c0 = reinterpret_cast<float4*>(row0 + 2 * col) + 2 * lane;
+            c0[0] = make_float4(v.x, v.y, dq.x, dq.y);
+            c0[1] = make_float4(v.z, v.w, dq.z, dq.w);
+            float4* c1 = reinterpret_cast<float4*>(row0 + 2 * rs + 2 * col) + 2 * lane;
+            c1[0] = make_float4(pw, v.x, dw, dq.x);
+            c1[1] = make_float4(v.y, v.z, dq.y, dq.z);
+        } else {
+            write_copies<C>(row0, rs, col, lane, v, 0.0f, 0.0f, pw);
         }
-        if (wipe && my_seg == 0) {
-            // the zero prefix: only the parked rows of the power pass ever overwrite it -- restored on a group's first visit of a half
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int q = lane; q < (lead >> 2); q += kWave) {
+    };
+    // the zero prefix of both halves' rows of this wave's mic: only the parked rows of the power pass ever overwrite it
+    // (pad: C rows of rs floats; lerp: C rows of 2 rs floats -- `lead` samples are lead / 4 resp. lead / 2 quads)
+    auto wipe_prefix = [&]() {
+        const int lane = lane_id();
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int c = 0; c < C * A; ++c) reinterpret_cast<float4*>(row0 + c * rs)[q] = z;
+        for (int hh = 0; hh < 2; ++hh) {
+            float* row0 = lds + (hh * HC + my_mic) * slot_floats;
+            for (int q = lane; q < ((A * lead) >> 2); q += kWave) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) reinterpret_cast<float4*>(row0 + c * A * rs)[q] = z;
             }
         }
     };
 
-    Staged st = fetch(0);
-    const int lb = 8 * lane + (int)(unsigned)(size_t)((__attribute__((address_space(3))) char*)lds);
-    const int d_off = 4 * C * rs;                               // D copies sit C rows after the s copies
+    Staged st = fetch_next();
+    const int lb = (kLerp ? 16 : 8) * lane + (int)(unsigned)(size_t)((__attribute__((address_space(3))) char*)lds);
+    [[maybe_unused]] const int d_off = 0;
 
     for (int g0 = tile_begin; g0 < tile_end; g0 += kGroup) {
         f32x2 acc[DW][NSEG][2];
@@ -2697,8 +2855,9 @@ __global__ void __launch_bounds__(1024, 4) das_long_kernel(BF_TABLE_PARAMS, KArg
             for (int sg = 0; sg < NSEG; ++sg) { acc[j][sg][0] = f32x2{0.0f, 0.0f}; acc[j][sg][1] = f32x2{0.0f, 0.0f}; }
 
         __syncthreads();   // the previous group's parked rows have been summed
-        stage(0, st, true);
-        st = fetch(1 % n_half);
+        if (my_seg == 0) wipe_prefix();
+        stage(0, st);
+        st = fetch_next();                                      // half 1 (a single half: half 0 again, the next group's)
         const int dw0 = g0 + wave * DW;                         // wave-uniform
         const bool busy = dw0 < tile_end;                       // this wave has directions in the tile
         const size_t grp = busy ? (size_t)(dw0 - a.dir_begin) / DW : 0;
@@ -2715,25 +2874,38 @@ __global__ void __launch_bounds__(1024, 4) das_long_kernel(BF_TABLE_PARAMS, KArg
                 if constexpr (kLerp) t.hp[j] = *reinterpret_cast<const unsigned long long*>(ht + m * DW + 2 * j);
             }
         };
-        // table entries two mics ahead, three sets in rotation; the pipeline runs on across the halves' barriers
-        Entries E[3];
+        // table entries two mics ahead, KE sets in rotation; the pipeline runs on across the halves' barriers
+        // (4 mics per half: four sets, a mic's set is m % 4 in every half; 8 mics per half: three sets and a move at the half's end)
+        constexpr int KE = HC == 4 ? 4 : 3;
+        Entries E[KE];
         request(E[0], 0);
         request(E[1], 1);
         __syncthreads();
 
         for (int h = 0; h < n_half; ++h) {
             if (h + 1 < n_half) {
-                stage(h + 1, st, h == 0);                       // into the half whose sweeps ended before the last barrier
-                if (h + 2 < n_half) st = fetch(h + 2);
-                else if (g0 + kGroup < tile_end) st = fetch(0);
+                stage(h + 1, st);                               // into the half whose sweeps ended before the last barrier
+                st = fetch_next();                              // half h + 2, or half 0 for the next group (read for nothing after the last group)
             }
             if (busy) {
                 Quad S[NSEG], Dq[NSEG];
 #pragma unroll
                 for (int sg = 0; sg < NSEG; ++sg) S[sg].lo = S[sg].hi = Dq[sg].lo = Dq[sg].hi = f32x2{0.0f, 0.0f};
-                auto mic = [&](int m, auto kc) {
-                    constexpr int K = decltype(kc)::value, K2 = (K + 2) % 3;
+                auto mic = [&](int m, auto kc, auto pc) {
+                    constexpr int K = decltype(kc)::value, K2 = (K + 2) % KE, POS = decltype(pc)::value;   // POS: the mic's place in its half
                     const Entries& cur = E[K];
+                    if constexpr (kLerp) {
+                        // The first mic of a half reads its quads itself; every other mic's reads were issued by its predecessor's last
+                        // step.  Step 0 ends with everything landed (its last wait is lgkmcnt(0)); the s_waitcnt behind it costs nothing
+                        // and tells the compiler so -- the entries of the next two mics are usable from here on.
+                        if constexpr (POS == 0) long_lerp_first<NSEG>(acc, cur.e[0], cur.hp[0], lb);
+                        else long_lerp_cont<NSEG>(acc, cur.hp[0]);
+                        __builtin_amdgcn_s_waitcnt(0xC07F);
+                        request(E[K2], m + 2);
+                        if constexpr (POS == HC - 1) long_lerp_rest<NSEG, false>(acc, cur.e, cur.hp, lb, 0);
+                        else long_lerp_rest<NSEG, true>(acc, cur.e, cur.hp, lb, E[(K + 1) % KE].e[0]);
+                        return;
+                    }
                     __builtin_amdgcn_s_waitcnt(0xC07F);         // this mic's entries (requested two mics ago) have landed
                     load_quads_cf<NSEG, kLerp>(S, Dq, cur.e[0], lb, d_off);
                     request(E[K2], m + 2);                      // after the reads' wait, so that it does not sit on these loads
@@ -2758,13 +2930,19 @@ __global__ void __launch_bounds__(1024, 4) das_long_kernel(BF_TABLE_PARAMS, KArg
                     }
                 };
                 using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+                using I3 = std::integral_constant<int, 3>;
                 const int m0 = h * HC;
-                // HC mics: entry sets rotate K = m % 3 from 0 at the start of every half ...
-                mic(m0 + 0, I0{}); mic(m0 + 1, I1{}); mic(m0 + 2, I2{}); mic(m0 + 3, I0{});
-                if constexpr (HC == 8) { mic(m0 + 4, I1{}); mic(m0 + 5, I2{}); mic(m0 + 6, I0{}); mic(m0 + 7, I1{}); }
-                // ... so the two sets already requested for the next half's first mics move to slots 0 and 1 (scalar moves)
-                if constexpr (HC == 4) { E[0] = E[1]; E[1] = E[2]; }                      // mics m0 + 4, m0 + 5 sit in sets (4 % 3, 5 % 3) = (1, 2)
-                else { const Entries t = E[0]; E[0] = E[2]; E[1] = t; }                  // mics m0 + 8, m0 + 9 sit in sets (8 % 3, 9 % 3) = (2, 0)
+                if constexpr (HC == 4) {
+                    mic(m0 + 0, I0{}, I0{}); mic(m0 + 1, I1{}, I1{}); mic(m0 + 2, I2{}, I2{}); mic(m0 + 3, I3{}, I3{});
+                } else {
+                    // entry sets rotate K = m % 3 from 0 at the start of every half ...
+                    using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>; using I6 = std::integral_constant<int, 6>;
+                    using I7 = std::integral_constant<int, 7>;
+                    mic(m0 + 0, I0{}, I0{}); mic(m0 + 1, I1{}, I1{}); mic(m0 + 2, I2{}, I2{}); mic(m0 + 3, I0{}, I3{});
+                    mic(m0 + 4, I1{}, I4{}); mic(m0 + 5, I2{}, I5{}); mic(m0 + 6, I0{}, I6{}); mic(m0 + 7, I1{}, I7{});
+                    // ... so the two sets already requested for the next half's first mics (8 % 3, 9 % 3) = (2, 0) move to slots 0 and 1
+                    const Entries t = E[0]; E[0] = E[2]; E[1] = t;
+                }
             }
             __syncthreads();   // half h is free, half h + 1 is staged
         }
@@ -2909,7 +3087,7 @@ hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, in
                     if (L.tab.digest == nullptr || L.tab.digest_direct || plan.waves != copies::kWaves || plan.mic_chunk != LG::kMc ||
                         (L.n_mics % LG::kHalf) != 0 || plan.dpw != LG::kDw)
                         return hipErrorInvalidValue;
-                    const bool fixed_rs = plan.row_stride == copies::Geo<NSEG>::kRs && plan.lead == copies::Geo<NSEG>::kLead;
+                    const bool fixed_rs = plan.row_stride == (LG::kLerp ? 2 : 1) * copies::Geo<NSEG>::kRs && plan.lead == copies::Geo<NSEG>::kLead;
                     auto kernel = fixed_rs ? copies::das_long_kernel<ALGO, NSEG, copies::Geo<NSEG>::kRs> : copies::das_long_kernel<ALGO, NSEG, 0>;
                     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
                     if (e != hipSuccess) return e;
@@ -3140,9 +3318,13 @@ int plan_das(const DasLaunch& L, int n_cus, DasPlan* plan, const char** why)
         p.long_rows = 0;
         if (plain && nseg > 1 && !L.tab.digest_direct && !(L.debug & 4096)) {
             const int half = 16 / nseg;
-            if ((L.n_mics % half) == 0 && slot_bytes * (size_t)(2 * half) <= (size_t)160 * 1024) {
+            if ((L.n_mics % half) == 0 && (L.n_samples % 4) == 0 && slot_bytes * (size_t)(2 * half) <= (size_t)160 * 1024) {
                 p.long_rows = 1;
                 mc = 2 * half;
+                if (L.algo == ALGO_LERP) {                      // rows of (sample pair, difference pair) quads: two floats per sample, no separate difference rows
+                    p.interleaved = 1;
+                    p.row_stride *= 2;
+                }
             }
         }
         p.mic_chunk = mc; p.n_chunks = (L.n_mics + mc - 1) / mc;
@@ -3234,7 +3416,8 @@ hipError_t launch_digest(const DasLaunch& L, const DasPlan& plan, int32_t* d_dig
     // s[k - p - 1 - T/2] (T = 8)
     // (`arrays`: rows of one staged mic in units of its shifted copies -- samples, lerp's differences, and both frames of the pair kernel)
     // (the hybrid pair kernel interleaves its two frames inside a row: one array per mic)
-    const int arrays = ((L.algo == ALGO_LERP) ? 2 : 1) * ((plan.nf == 2 && !plan.interleaved) ? 2 : 1), bias = (L.algo == ALGO_LERP) ? 1 : (L.algo == ALGO_HYBRID) ? 5 : 0;
+    // (das_long_kernel's lerp rows carry their differences inside: one array)
+    const int arrays = ((L.algo == ALGO_LERP && !(plan.long_rows && plan.interleaved)) ? 2 : 1) * ((plan.nf == 2 && !plan.interleaved) ? 2 : 1), bias = (L.algo == ALGO_LERP) ? 1 : (L.algo == ALGO_HYBRID) ? 5 : 0;
     const bool fir_pair = plan.nf == 2 && (L.algo == ALGO_HYBRID || L.algo == ALGO_FIR_NAIVE || L.algo == ALGO_FIR_VEC);
     if ((L.algo == ALGO_HYBRID && plan.nf != 2) || direct) {
         hipLaunchKernelGGL(digest_kernel, dim3(1024), dim3(256), 0, stream, L.tab.whole, d_digest, (long long)L.n_dirs * L.n_mics, L.n_mics, plan.mic_chunk,
