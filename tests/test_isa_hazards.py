@@ -67,8 +67,8 @@ def test_no_register_with_a_read_in_flight_is_touched(chk, asm):
 def test_every_launchable_instantiation_is_scanned_and_none_that_pipelines_reads_spills(chk, asm):
     """launch_nc (das_kernels.hip) can pick: the pair kernel (pad, lerp); the one-frame sweep for 1 / 2 / 4 segments with the fixed or
     the run-time row stride, 16 waves -- one segment also with 8 waves -- and its direction-outer (DIRECT) twin; the three 8-tap FIR
-    flavours.  The instantiations that keep LDS reads in flight across asm statements (pair kernel; one-segment sweep) must not
-    use scratch: a spilled register with a read in flight is reloaded before the data lands."""
+    flavours.  The instantiations that keep LDS reads in flight across asm statements (pair kernel; one-segment sweep; the long-row
+    kernel, whose lerp sweep issues a mic's reads behind its predecessor's last step) must not use scratch: a spilled register with a read in flight is reloaded before the data lands."""
     md = chk.metadata(asm)
     names = [n for n in md if any(k in n for k in ("das_copies_kernel", "das_pair_kernel", "das_pair2_kernel", "das_long_kernel", "das_hybrid_pair_kernel"))]
     short = dict(zip(chk.demangle(names), names))
@@ -83,9 +83,9 @@ def test_every_launchable_instantiation_is_scanned_and_none_that_pipelines_reads
     assert not missing, missing
     kernels, _ = chk.scan(asm)
     assert kernels == len(names)                       # the scan covered every one of them
-    pipelined = [w for w in want if "bf::copies::das_pair_kernel" in w or (w.startswith("bf::copies::das_copies_kernel<0, 1,") or w.startswith("bf::copies::das_copies_kernel<1, 1,"))
-                 and w.endswith("false>")]
-    assert len(pipelined) == 2 + 2 * 4
+    pipelined = [w for w in want if "bf::copies::das_pair_kernel" in w or "bf::copies::das_long_kernel" in w or
+                 (w.startswith("bf::copies::das_copies_kernel<0, 1,") or w.startswith("bf::copies::das_copies_kernel<1, 1,")) and w.endswith("false>")]
+    assert len(pipelined) == 2 + 8 + 2 * 4
     for w in pipelined:
         m = md[short[w]]
         assert m["spill"] == 0 and m["scratch"] == 0, (w, m)

@@ -2843,7 +2843,6 @@ __global__ void __launch_bounds__(1024, 4) das_long_kernel(BF_TABLE_PARAMS, KArg
         }
     };
 
-    Staged st = fetch_next();
     const int lb = (kLerp ? 16 : 8) * lane + (int)(unsigned)(size_t)((__attribute__((address_space(3))) char*)lds);
     [[maybe_unused]] const int d_off = 0;
 
@@ -2856,8 +2855,11 @@ __global__ void __launch_bounds__(1024, 4) das_long_kernel(BF_TABLE_PARAMS, KArg
 
         __syncthreads();   // the previous group's parked rows have been summed
         if (my_seg == 0) wipe_prefix();
+        // (half 0 is fetched here, not under the previous group's last half: five registers less to carry through the power pass, which
+        //  is where the kernel used to spill; the exposed load is one in M / HC halves)
+        Staged st = fetch_next();
         stage(0, st);
-        st = fetch_next();                                      // half 1 (a single half: half 0 again, the next group's)
+        st = fetch_next();                                      // half 1 (a single half: half 0 again, for nothing)
         const int dw0 = g0 + wave * DW;                         // wave-uniform
         const bool busy = dw0 < tile_end;                       // this wave has directions in the tile
         const size_t grp = busy ? (size_t)(dw0 - a.dir_begin) / DW : 0;
@@ -2885,7 +2887,7 @@ __global__ void __launch_bounds__(1024, 4) das_long_kernel(BF_TABLE_PARAMS, KArg
         for (int h = 0; h < n_half; ++h) {
             if (h + 1 < n_half) {
                 stage(h + 1, st);                               // into the half whose sweeps ended before the last barrier
-                st = fetch_next();                              // half h + 2, or half 0 for the next group (read for nothing after the last group)
+                if (h + 2 < n_half) st = fetch_next();          // half h + 2
             }
             if (busy) {
                 Quad S[NSEG], Dq[NSEG];
@@ -2949,47 +2951,37 @@ __global__ void __launch_bounds__(1024, 4) das_long_kernel(BF_TABLE_PARAMS, KArg
 
         // ---- k-ordered mean power (pad_and_sum.c:120-128): a.pbw waves at a time park the squared means of their directions
         // (row = direction, k in order; the rows alias the LDS image), then one direction per lane runs the sequential sum.
-        // The squares replace the accumulators IN PLACE first: computed inside the rounds they are loop-invariant, and the
-        // compiler hoists all 64 of them out of the loop -- into scratch.
-        {
-            auto square = [&](auto mul_c) __attribute__((always_inline)) {   // (a call would force the accumulators into memory)
-#pragma unroll
-                for (int j = 0; j < DW; ++j) {
-#pragma unroll
-                    for (int sg = 0; sg < NSEG; ++sg) {
-                        // mean over the mics: a power-of-two count multiplies (exact), anything else divides like the reference
-                        const f32x2 a0 = acc[j][sg][0], a1 = acc[j][sg][1];
-                        float o0, o1, o2, o3;
-                        if constexpr (decltype(mul_c)::value) {
-                            o0 = a0.x * a.inv_n; o1 = a0.y * a.inv_n; o2 = a1.x * a.inv_n; o3 = a1.y * a.inv_n;
-                        } else {
-                            float fm = (float)M;
-                            asm volatile("" : "+v"(fm));   // not speculatable: keeps this path behind its branch
-                            o0 = a0.x / fm; o1 = a0.y / fm; o2 = a1.x / fm; o3 = a1.y / fm;
-                            __builtin_amdgcn_sched_barrier(0);   // one quad's divisions at a time: interleaved, their temporaries spill
-                        }
-                        acc[j][sg][0] = f32x2{o0 * o0, o1 * o1};
-                        acc[j][sg][1] = f32x2{o2 * o2, o3 * o3};
-                    }
-                }
-            };
-            if (__builtin_expect(a.n_is_pow2, 1)) square(std::true_type{}); else square(std::false_type{});
-        }
+        // The squares are computed where they are stored, behind an opaque pass of the accumulators through an empty asm: without it
+        // they are loop-invariant in the rounds loop and the compiler hoists all 64 of them out of it -- into scratch.
         const int pw_waves = a.pbw;
         for (int w0 = 0; w0 < W; w0 += pw_waves) {
             if (w0 > 0) __syncthreads();                        // the previous round's rows have been summed
             if (wave >= w0 && wave < w0 + pw_waves) {
+                auto park = [&](auto mul_c) __attribute__((always_inline)) {   // (a call would force the accumulators into memory)
 #pragma unroll
-                for (int j = 0; j < DW; ++j) {
-                    float* row = lds + ((wave - w0) * DW + j) * kPark;
+                    for (int j = 0; j < DW; ++j) {
+                        float* row = lds + ((wave - w0) * DW + j) * kPark;
 #pragma unroll
-                    for (int sg = 0; sg < NSEG; ++sg) {
-                        // samples (2l, 2l+1) and (128+2l, 128+2l+1) of the segment
-                        const f32x2 a0 = acc[j][sg][0], a1 = acc[j][sg][1];
-                        reinterpret_cast<float2*>(row + 256 * sg)[lane] = make_float2(a0.x, a0.y);
-                        reinterpret_cast<float2*>(row + 256 * sg + 128)[lane] = make_float2(a1.x, a1.y);
+                        for (int sg = 0; sg < NSEG; ++sg) {
+                            f32x2 a0 = acc[j][sg][0], a1 = acc[j][sg][1];
+                            asm volatile("" : "+v"(a0), "+v"(a1));
+                            // mean over the mics: a power-of-two count multiplies (exact), anything else divides like the reference
+                            float o0, o1, o2, o3;
+                            if constexpr (decltype(mul_c)::value) {
+                                o0 = a0.x * a.inv_n; o1 = a0.y * a.inv_n; o2 = a1.x * a.inv_n; o3 = a1.y * a.inv_n;
+                            } else {
+                                float fm = (float)M;
+                                asm volatile("" : "+v"(fm));   // not speculatable: keeps this path behind its branch
+                                o0 = a0.x / fm; o1 = a0.y / fm; o2 = a1.x / fm; o3 = a1.y / fm;
+                                __builtin_amdgcn_sched_barrier(0);   // one quad's divisions at a time: interleaved, their temporaries spill
+                            }
+                            // samples (2l, 2l+1) and (128+2l, 128+2l+1) of the segment
+                            reinterpret_cast<float2*>(row + 256 * sg)[lane] = make_float2(o0 * o0, o1 * o1);
+                            reinterpret_cast<float2*>(row + 256 * sg + 128)[lane] = make_float2(o2 * o2, o3 * o3);
+                        }
                     }
-                }
+                };
+                if (__builtin_expect(a.n_is_pow2, 1)) park(std::true_type{}); else park(std::false_type{});
             }
             __syncthreads();
             const int g = wave * kWave + lane;                  // parked row of this lane
