@@ -174,10 +174,11 @@ def extras(torch, nat, delays, mics, dev):
     win = torch.from_numpy(synth.frame_batch(M, N, Bf)).to(dev)
     cam = torch.randint(0, 256, (Bf, 640, 640, 3), dtype=torch.uint8, device=dev)
     dt = timed(lambda: pipe.step(win, cam), torch, 10)
-    out["fused_heatmap_overlay_yolo"] = {"frames_per_s": Bf / dt, "batch": Bf, "image": "640x640x3 uint8", "detector": "YOLOv5s-shaped, fp16 (ultralytics' default predict is fp32), random init, 1 class"}
+    out["fused_heatmap_overlay_yolo"] = {"frames_per_s": Bf / dt, "batch": Bf, "image": "640x640x3 uint8", "detector": "YOLOv5s-shaped, fp16 (ultralytics' default predict is fp32), random init, 1 class",
+                                         "conv_backend": pipe.detector.conv_backend}
     x = pipe.detector.preprocess(cam)
     dt = timed(lambda: pipe.detector.postprocess(pipe.detector.raw(x)), torch, 10)
-    out["yolo_only"] = {"detections_per_s": Bf / dt, "batch": Bf, "gflop_per_frame": 15.8, "dtype": "fp16"}
+    out["yolo_only"] = {"detections_per_s": Bf / dt, "batch": Bf, "gflop_per_frame": 15.8, "dtype": "fp16", "conv_backend": pipe.detector.conv_backend}
     # config 3 + frequency-domain DAS: same 64-mic array and 101x101 grid through the frequency-domain geometry
     old = (C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y)
     C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y = 64, 1, 101, 101

@@ -234,6 +234,16 @@ int bf_yolo_decode_device(const void *const raw[3], const int h[3], const int w[
  *       bitonic sort in LDS.  This is the candidate list bf_nms_device walks. */
 int bf_topk_candidates_device(const float *d_scores, const float *d_boxes, const int *d_cls, int batch, int total, int k, float *d_top_scores,
                               float *d_top_boxes, int *d_top_cls, int *d_counts, void *stream);
+/*   bf_conv2d_nhwc_f16_device: the detector's convolutions (the network behind ultralytics.YOLO, yolo_smooth_tracking.py:9-23) as an
+ *       implicit GEMM on the f16 matrix cores: y[b][ho][wo][n] = act(bias[n] + sum x[b][ho*stride-pad+i][wo*stride-pad+j][c] * w[n][i][j][c]),
+ *       x float16 NHWC [batch][h][w][c]; w float16 [n][kh][kw][c], every output channel's kh*kw*c values followed by zeros up to a
+ *       multiple of 32 (bf_conv2d_weight_row(kh, kw, c) halfs per row); bias float32 [n] or NULL; y float16 NHWC
+ *       [batch][(h+2*pad-kh)/stride+1][(w+2*pad-kw)/stride+1][n]; silu != 0 applies x*sigmoid(x) (f32 accumulation throughout).
+ *       c a power of two >= 4 with kw * c a multiple of 8 (pad a 3-channel image with one zero channel; 4 channels need even
+ *       stride, pad and width). */
+int bf_conv2d_weight_row(int kh, int kw, int c);
+int bf_conv2d_nhwc_f16_device(const void *d_x, const void *d_w, const float *d_bias, void *d_y, int batch, int h, int w, int c, int n, int kh, int kw,
+                              int stride, int pad, int silu, void *stream);
 int bf_nms_device(const float *d_boxes, const float *d_scores, const int *d_cls, const int *d_counts, int batch, int k, float iou_thres, int max_det,
                   unsigned long long *d_mask, float *d_out, int *d_out_count, void *stream);
 

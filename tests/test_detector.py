@@ -155,3 +155,69 @@ def test_gpu_topk_candidates_match_numpy(native, B, T, K):
         assert np.array_equal(top[b, :keff], scores[b][order]), b
         assert np.array_equal(tb[b, :keff], boxes[b][order]) and np.array_equal(tc[b, :keff], cls[b][order])
         assert (top[b, keff:] == -1).all() and cnt[b] == int((scores[b][order] > 0).sum())
+
+
+# ---- the detector's convolutions as this library's implicit-GEMM kernel (csrc/conv_kernels.hip)
+
+CONV_CASES = [  # (B, Cin, H, W, Cout, k, stride, pad, silu)      the layer shapes of yolov5s.py plus ragged tiles
+    (2, 3, 64, 96, 32, 6, 2, 2, True),        # the stem: 3 channels padded to 16, 6x6 window, stride 2
+    (2, 32, 40, 40, 64, 3, 2, 1, True),       # a strided 3x3
+    (1, 64, 20, 28, 64, 3, 1, 1, True),       # a bottleneck 3x3
+    (3, 128, 17, 13, 64, 1, 1, 0, True),      # 1x1; 663 pixels: a ragged last pixel tile
+    (1, 1024, 10, 10, 512, 1, 1, 0, True),    # SPPF's second 1x1: the deepest K
+    (2, 256, 16, 16, 18, 1, 1, 0, False),     # a detect level: 18 outputs (a ragged channel tile), bias only
+    (1, 512, 7, 9, 512, 3, 2, 1, True),       # odd sizes under stride 2
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,H,W,N,k,s,p,silu", CONV_CASES)
+def test_gpu_hip_convolution_matches_torch_fp32(native, B, C, H, W, N, k, s, p, silu):
+    """bf_conv2d_nhwc_f16_device (through yolov5s.HipConv) against torch's fp32 convolution of the same float16 operands.
+    Tolerance: the kernel accumulates in f32 and rounds once to f16 -> 2^-10 relative to the layer's largest output, plus the
+    fp16 rounding of the result itself."""
+    import torch
+    from image_detection.model import yolov5s
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + C + N)
+    conv = torch.nn.Conv2d(C, N, k, s, p, bias=True)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / (C * k * k) ** 0.5)
+        conv.bias.copy_(torch.randn(conv.bias.shape, generator=g) * 0.5)
+    conv = conv.cuda().half()
+    x = (torch.randn((B, C, H, W), generator=g) * 1.5).cuda().half().contiguous(memory_format=torch.channels_last)
+    got = yolov5s.HipConv(conv, silu)(x)
+    want = torch.nn.functional.conv2d(x.float(), conv.weight.float(), conv.bias.float(), s, p)
+    if silu:
+        want = torch.nn.functional.silu(want)
+    assert got.shape == want.shape and got.dtype == torch.float16 and got.is_contiguous(memory_format=torch.channels_last)
+    err = (got.float() - want).abs().max().item() / want.abs().max().item()
+    assert err < 2e-3, err
+
+
+@pytest.mark.gpu
+def test_gpu_network_on_hip_convolutions(native):
+    """The whole YOLOv5s-shaped network with every convolution on the library's kernel: head logits agree with the fp32 forward
+    to fp16 accuracy (the same bound the MIOpen path is held to), and with the MIOpen fp16 forward."""
+    import torch
+    from image_detection.model import yolov5s
+    x = torch.rand((2, 3, 640, 640), device="cuda")
+    xh = x.half().contiguous(memory_format=torch.channels_last)
+    ref = yolov5s.build(half=False)(x)
+    mi = yolov5s.build(half=True)(xh)
+    net = yolov5s.build(half=True, conv_backend="hip")
+    assert sum(isinstance(m, yolov5s.HipConv) for m in net.modules()) == 60 and not any(isinstance(m, torch.nn.Conv2d) for m in net.modules())
+    got = net(xh)
+    for a, b, c in zip(got, ref, mi):
+        assert a.shape == b.shape
+        assert (a.float() - b).abs().max().item() / b.abs().max().item() < 3e-2
+        assert (a.float() - c.float()).abs().max().item() / b.abs().max().item() < 3e-2
+
+
+@pytest.mark.gpu
+def test_gpu_detector_backends_agree(native):
+    import torch
+    from image_detection.src.yolo_smooth_tracking import Detector
+    frames = torch.randint(0, 256, (2, 320, 320, 3), dtype=torch.uint8, device="cuda")
+    a, na = Detector(conv_backend="miopen").detect(frames, conf_thres=0.001)
+    b, nb = Detector(conv_backend="hip").detect(frames, conf_thres=0.001)
+    assert a.shape == b.shape and torch.equal(na > 0, nb > 0)

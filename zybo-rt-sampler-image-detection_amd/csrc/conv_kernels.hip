@@ -1,0 +1,180 @@
+// Convolution + bias + SiLU of the detector (image_detection/model/yolov5s.py) as one implicit-GEMM kernel on the f16 matrix cores.
+//
+// The reference calls `ultralytics.YOLO(...)` (image-detection/src/yolo_smooth_tracking.py:9-23); its network is the published
+// YOLOv5s graph: 60 convolutions with 1x1, 3x3 and one 6x6 window, stride 1 or 2, each followed (BatchNorm folded) by a bias and SiLU,
+// plus three plain 1x1 detect convolutions.  All of them are this kernel:
+//
+//   out[b, ho, wo, n] = act( bias[n] + sum_{kh, kw, c} in[b, ho s - p + kh, wo s - p + kw, c] * w[n, kh, kw, c] )
+//
+// as a GEMM  [M = B Ho Wo pixels] x [K = KH KW C] x [N = Cout]  on v_mfma_f32_32x32x16_f16 (f16 operands, f32 accumulation):
+//   * activations are NHWC (torch channels_last), so for one kh the KW x C operands of an output pixel are ONE contiguous run of the
+//     input row; the weights are packed [Cout][KH][KW][C], the same K order, each row zero-padded to whole stages.  C is a power of
+//     two: from 8 up every 16-byte chunk of 8 halfs lies inside one input pixel; C = 4 (the 3-channel image padded by one) makes
+//     a chunk two neighbouring pixels, which the 6x6 / stride 2 / pad 2 stem keeps inside or outside the image together (even
+//     window start, even width).  Either way the zero padding of the window is a per-chunk mask;
+//   * a workgroup of 4 waves owns a 128-pixel x 64-channel output tile; K advances 32 per stage through two LDS buffers (one barrier per
+//     stage): every thread moves two 16-byte chunks of the pixel tile and one of the weight tile, global -> registers (issued a stage
+//     ahead) -> LDS; rows are padded to 80 bytes, which spreads a wave's 16-byte fragment reads over all banks;
+//   * a wave owns 32 pixels x 64 channels: per 16-deep step one A fragment and two B fragments (ds_read_b128) feed two MFMAs;
+//   * the epilogue adds the bias, applies SiLU (x / (1 + exp(-x))), rounds to f16 and transposes the tile through LDS so that every
+//     thread stores 16 contiguous bytes of a pixel's channels (the 1x1 layers are bound by these stores).
+// Parity: tests/test_detector.py compares against torch's fp32 convolution of the same f16 operands.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cstdint>
+
+#include "das_kernels.h"
+
+namespace bf {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+constexpr int kBM = 128, kBN = 64, kBK = 32, kRow = kBK + 8;   // halfs per LDS row (80 bytes)
+
+struct ConvArgs {
+    int B, H, W, C, Ho, Wo, N, KH, KW, stride, pad, act;
+    int c_shift;          // log2(C)
+    long long M;          // B * Ho * Wo
+};
+
+__global__ void __launch_bounds__(256) conv_igemm_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const float* __restrict__ bias,
+                                                         _Float16* __restrict__ y, ConvArgs a)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 As[2][kBM * kRow];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][kBN * kRow];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long m0 = (long long)blockIdx.x * kBM;
+    const int n0 = blockIdx.y * kBN;
+    // K is walked in 16-byte chunks of 8 halfs: chunk q = (kh, 8 (q % cpk) halfs into the kh run of KW * C); 4 chunks per stage
+    const int cpk = (a.KW * a.C) >> 3, n_chunk = a.KH * cpk, n_stage = (n_chunk + 3) >> 2;
+
+    // this thread's chunks: pixel rows r and r + 64, chunk `ck` of the stage; weight row r, same chunk
+    const int r = tid >> 2, ck = tid & 3;
+    int hi0[2], wi0[2];
+    const _Float16* px[2];
+    bool pv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long long m = m0 + r + 64 * i;
+        pv[i] = m < a.M;
+        const unsigned mm = pv[i] ? (unsigned)m : 0u;          // (M < 2^31: launch_conv2d_nhwc_f16)
+        const unsigned b = mm / (unsigned)(a.Wo * a.Ho), rem = mm - b * (unsigned)(a.Wo * a.Ho);
+        const unsigned ho = rem / (unsigned)a.Wo, wo = rem - ho * (unsigned)a.Wo;
+        hi0[i] = (int)ho * a.stride - a.pad;
+        wi0[i] = (int)wo * a.stride - a.pad;
+        px[i] = x + (size_t)b * a.H * a.W * a.C;
+    }
+    const bool wv = n0 + r < a.N;
+    const _Float16* wrow = w + (size_t)(wv ? n0 + r : 0) * n_stage * kBK;      // weight rows are padded to whole stages
+
+    half8 ra[2], rb;
+    bool oka[2];          // (the zero padding is applied when the chunk goes to LDS: a select right behind the load would wait for it there)
+    auto fetch = [&](int s) {
+        const int q = 4 * s + ck;
+        const int kh = q / cpk, kk = (q - kh * cpk) << 3;      // halfs into the kh run
+        const int kw = kk >> a.c_shift, c = kk & (a.C - 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hi = hi0[i] + kh, wi = wi0[i] + kw;
+            const bool ok = pv[i] && q < n_chunk && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            const size_t off = ok ? ((size_t)hi * a.W + wi) * a.C + c : 0;
+            ra[i] = *reinterpret_cast<const half8*>(px[i] + off);
+            oka[i] = ok;
+        }
+        rb = *reinterpret_cast<const half8*>(wrow + (size_t)q * 8);
+    };
+    auto stash = [&](int buf) {
+        const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        *reinterpret_cast<half8*>(&As[buf][r * kRow + ck * 8]) = oka[0] ? ra[0] : z;
+        *reinterpret_cast<half8*>(&As[buf][(r + 64) * kRow + ck * 8]) = oka[1] ? ra[1] : z;
+        *reinterpret_cast<half8*>(&Bs[buf][r * kRow + ck * 8]) = wv ? rb : z;
+    };
+
+    float16v acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int s = 0; s < n_stage; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < n_stage) fetch(s + 1);                     // in flight under this stage's MFMAs
+        const _Float16* A = &As[buf][(wave * 32 + (lane & 31)) * kRow + 8 * (lane >> 5)];
+        const _Float16* Bp = &Bs[buf][(lane & 31) * kRow + 8 * (lane >> 5)];
+#pragma unroll
+        for (int k16 = 0; k16 < kBK / 16; ++k16) {
+            const half8 af = *reinterpret_cast<const half8*>(A + 16 * k16);
+            const half8 b0 = *reinterpret_cast<const half8*>(Bp + 16 * k16);
+            const half8 b1 = *reinterpret_cast<const half8*>(Bp + 32 * kRow + 16 * k16);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b1, acc[1], 0, 0, 0);
+        }
+        if (s + 1 < n_stage) stash(buf ^ 1);                   // the other buffer: its readers passed the previous barrier
+        __syncthreads();
+    }
+
+    // Epilogue.  C lane map of v_mfma_f32_32x32x16_f16: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    // The f16 tile goes through LDS (the pixel tile's buffers are free after the loop's last barrier): rows of 64 channels + 8.
+    constexpr int kCRow = kBN + 8;
+    _Float16* Cs = &As[0][0];
+    static_assert(kBM * kCRow <= 2 * kBM * kRow, "the output tile fits the pixel tile's two buffers");
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = n0 + 32 * t + (lane & 31);
+        const float bn = (bias && n < a.N) ? bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float v = acc[t][i] + bn;
+            if (a.act) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));      // SiLU (1 ulp reciprocal, rounded to f16 next)
+            Cs[(wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * kCRow + 32 * t + (lane & 31)] = (_Float16)v;
+        }
+    }
+    __syncthreads();
+    const bool wide = (a.N & 7) == 0;                          // 16-byte stores need 16-byte rows
+#pragma unroll
+    for (int j = 0; j < (kBM * kBN / 8) / 256; ++j) {
+        const int id = tid + 256 * j, row = id >> 3, cc = (id & 7) * 8;
+        const long long m = m0 + row;
+        if (m >= a.M || n0 + cc >= a.N) continue;
+        const _Float16* src = &Cs[row * kCRow + cc];
+        _Float16* dst = y + (size_t)m * a.N + n0 + cc;
+        if (wide) {
+            *reinterpret_cast<half8*>(dst) = *reinterpret_cast<const half8*>(src);
+        } else {
+            for (int e = 0; e < 8 && n0 + cc + e < a.N; ++e) dst[e] = src[e];
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_conv2d_nhwc_f16(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C, int N, int KH, int KW, int stride,
+                                  int pad, int act, hipStream_t stream)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || N <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return hipErrorInvalidValue;
+    if (C < 4 || (C & (C - 1)) != 0 || ((KW * C) & 7) != 0) return hipErrorInvalidValue;       // whole 16-byte chunks per window row
+    // C = 4: a chunk is two pixels, which must leave the image together -- even window starts, even width
+    if (C == 4 && ((stride & 1) || (pad & 1) || (W & 1))) return hipErrorInvalidValue;
+    ConvArgs a;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.act = act;
+    a.Ho = (H + 2 * pad - KH) / stride + 1;
+    a.Wo = (W + 2 * pad - KW) / stride + 1;
+    if (a.Ho <= 0 || a.Wo <= 0) return hipErrorInvalidValue;
+    a.c_shift = 0;
+    while ((1 << a.c_shift) < C) ++a.c_shift;
+    a.M = (long long)B * a.Ho * a.Wo;
+    if (a.M > 0x7fffffffLL) return hipErrorInvalidValue;       // (the kernel splits pixel indices in 32 bits)
+    const long long gx = (a.M + kBM - 1) / kBM;
+    const dim3 grid((unsigned)gx, (unsigned)((N + kBN - 1) / kBN));
+    hipLaunchKernelGGL(conv_igemm_kernel, grid, dim3(256), 0, stream, static_cast<const _Float16*>(x), static_cast<const _Float16*>(w), bias,
+                       static_cast<_Float16*>(y), a);
+    return hipGetLastError();
+}
+
+}  // namespace bf

@@ -4,8 +4,9 @@ The reference ships neither the architecture nor the weights (`image-detection/m
 .MISSING_LARGE_BLOBS; `ultralytics` is an unpinned third-party package), so this is the published YOLOv5s v6.x graph
 (depth 0.33, width 0.50: 6x6/2 stem, C3 stages 64-128-256-512, SPPF, PAN head, three detect levels at strides 8/16/32,
 anchors of the COCO release) with seeded random weights and `nc` classes (1 in the reference's use: drones).
-Convolutions run through MIOpen on the matrix cores (fp16, channels_last, BatchNorm folded); the head decode and the
-NMS are the hand-written HIP kernels of csrc/nms_kernels.hip."""
+Convolutions (fp16, channels_last, BatchNorm folded) run through the library's own implicit-GEMM MFMA kernel (`HipConv`,
+csrc/conv_kernels.hip: conv + bias + SiLU in one launch) or, with conv_backend="miopen", through torch / MIOpen; the head decode
+and the NMS are the hand-written HIP kernels of csrc/nms_kernels.hip."""
 import torch
 import torch.nn as nn
 
@@ -103,8 +104,62 @@ class YOLOv5s(nn.Module):
         return self
 
 
-def build(nc=1, seed=0, device="cuda", half=True):
-    """Seeded random-init network, inference mode, BatchNorm folded, fp16 channels_last on the GPU."""
+class HipConv(nn.Module):
+    """A folded convolution (+ SiLU) through the library's own kernel: bf_conv2d_nhwc_f16_device (csrc/conv_kernels.hip, implicit
+    GEMM on the f16 matrix cores).  In and out: [B, C, H, W] float16 tensors in channels_last memory, i.e. NHWC buffers.
+    The weights are repacked once to [N][KH][KW][C'] with C' = the input channels padded to what the kernel takes (the 3-channel
+    image of the 6x6 stem becomes 4 channels, the rest are powers of two already), each row zero-padded to whole K stages."""
+
+    def __init__(self, conv, silu):
+        super().__init__()
+        w = conv.weight.detach()
+        n, c, kh, kw = (int(v) for v in w.shape)
+        from lib import _native as nat
+        cp = 4
+        while cp < c or (kw * cp) % 8:
+            cp *= 2
+        wk = torch.zeros((n, kh, kw, cp), dtype=torch.float16, device=w.device)
+        wk[..., :c] = w.permute(0, 2, 3, 1).to(torch.float16)
+        wp = torch.zeros((n, nat.lib.bf_conv2d_weight_row(kh, kw, cp)), dtype=torch.float16, device=w.device)     # rows padded to whole K stages
+        wp[:, : kh * kw * cp] = wk.reshape(n, -1)
+        self.register_buffer("wp", wp.contiguous())
+        self.register_buffer("bias", None if conv.bias is None else conv.bias.detach().float().contiguous())
+        self.c, self.cp, self.n, self.kh, self.kw = c, cp, n, kh, kw
+        self.stride, self.pad, self.silu = int(conv.stride[0]), int(conv.padding[0]), 1 if silu else 0
+
+    def forward(self, x):
+        from lib import _native as nat
+        b, c, h, w = (int(v) for v in x.shape)
+        if x.dtype != torch.float16 or c != self.c:
+            raise nat.BeamformerError("HipConv: expects float16 input with %d channels, got %s with %d" % (self.c, x.dtype, c))
+        if c != self.cp:
+            xp = torch.empty((b, self.cp, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            xp[:, :c] = x
+            xp[:, c:] = 0
+            x = xp
+        elif not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        ho, wo = (h + 2 * self.pad - self.kh) // self.stride + 1, (w + 2 * self.pad - self.kw) // self.stride + 1
+        y = torch.empty((b, self.n, ho, wo), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+        if nat.lib.bf_conv2d_nhwc_f16_device(x.data_ptr(), self.wp.data_ptr(), None if self.bias is None else self.bias.data_ptr(), y.data_ptr(),
+                                             b, h, w, self.cp, self.n, self.kh, self.kw, self.stride, self.pad, self.silu,
+                                             torch.cuda.current_stream().cuda_stream) != 0:
+            nat.check()
+        return y
+
+
+def use_hip_convs(net):
+    """Route every convolution of a fused, half-precision network through HipConv (the SiLU moves into the kernel)."""
+    for m in net.modules():
+        if isinstance(m, Conv) and isinstance(m.conv, nn.Conv2d):
+            m.conv, m.act = HipConv(m.conv, True), nn.Identity()
+    net.detect = nn.ModuleList(HipConv(d, False) for d in net.detect)
+    return net
+
+
+def build(nc=1, seed=0, device="cuda", half=True, conv_backend="miopen"):
+    """Seeded random-init network, inference mode, BatchNorm folded, fp16 channels_last on the GPU.
+    conv_backend: "miopen" (torch's convolutions) or "hip" (this library's implicit-GEMM kernel; float16 only)."""
     torch.manual_seed(seed)
     net = YOLOv5s(nc)
     for m in net.modules():                      # give BatchNorm non-trivial statistics so that folding is exercised
@@ -118,4 +173,11 @@ def build(nc=1, seed=0, device="cuda", half=True):
     net = net.to(device)
     if half:
         net = net.half()
-    return net.to(memory_format=torch.channels_last)
+    net = net.to(memory_format=torch.channels_last)
+    if conv_backend == "hip":
+        if not half:
+            raise ValueError("the HIP convolution kernel computes in float16: build(half=True)")
+        net = use_hip_convs(net)
+    elif conv_backend != "miopen":
+        raise ValueError("conv_backend: 'miopen' or 'hip'")
+    return net

@@ -1,11 +1,13 @@
 """Mirror of the detection caller of the reference (image-detection/src/yolo_smooth_tracking.py): `yolo_model(path)
 .get_detections(frame, conf_threshold)` -> [[x1, y1, x2, y2, conf], ...] and `compute_iou`, with the network forward in
-PyTorch-ROCm and the head decode + NMS in the HIP kernels of csrc/nms_kernels.hip.
+PyTorch-ROCm -- its 60 convolutions (+ bias + SiLU) in the implicit-GEMM MFMA kernel of csrc/conv_kernels.hip -- and the head
+decode + candidate selection + NMS in the HIP kernels of csrc/nms_kernels.hip.
 
 `model_path` may name a state_dict saved from `image_detection.model.yolov5s.YOLOv5s`; with None (the reference's
 weights are not in its repository) a seeded random-init network is used.  SORT tracking (sort/sort.py, GPL, CPU) and the
 OpenCV drawing of `process_video_track_boxes_only` stay with the reference; `split_detections` is its banding logic."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -19,14 +21,22 @@ IOU_THRES, MAX_DET, MAX_NMS = 0.45, 300, 1024
 class Detector:
     """Batched device-resident detector: uint8/float frames already on the GPU in, [B, MAX_DET, 6] boxes + counts out."""
 
-    def __init__(self, model_path=None, nc=1, seed=0, device="cuda", half=True):
+    def __init__(self, model_path=None, nc=1, seed=0, device="cuda", half=True, conv_backend=None):
         import torch
         if not torch.cuda.is_available():
             raise nat.BeamformerError("no usable HIP device; the detector has no CPU path")
         self.torch, self.device, self.half, self.nc = torch, device, half, nc
-        self.net = yolov5s.build(nc, seed, device, half)
+        # conv_backend: "hip" = the library's implicit-GEMM kernel (csrc/conv_kernels.hip, float16 only; the default for half=True),
+        # "miopen" = torch's convolutions; BF_CONV_BACKEND overrides the default
+        backend = conv_backend or os.environ.get("BF_CONV_BACKEND", "hip" if half else "miopen")
+        self.net = yolov5s.build(nc, seed, device, half, "miopen")
         if model_path is not None:
             self.net.load_state_dict(torch.load(model_path, map_location=device))
+        if backend == "hip":
+            self.net = yolov5s.use_hip_convs(self.net)
+        elif backend != "miopen":
+            raise ValueError("conv_backend: 'miopen' or 'hip'")
+        self.conv_backend = backend
         self.anchors = np.ascontiguousarray(np.asarray(yolov5s.ANCHORS, dtype=np.float32).reshape(3, 3, 2))
         self._ws = {}
 
