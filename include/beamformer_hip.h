@@ -244,6 +244,12 @@ int bf_topk_candidates_device(const float *d_scores, const float *d_boxes, const
 int bf_conv2d_weight_row(int kh, int kw, int c);
 int bf_conv2d_nhwc_f16_device(const void *d_x, const void *d_w, const float *d_bias, void *d_y, int batch, int h, int w, int c, int n, int kh, int kw,
                               int stride, int pad, int silu, void *stream);
+/*   bf_conv2d_nhwc_f16_into_device: the same, writing into a channel slice of a wider NHWC buffer -- d_y points at the slice's first
+ *       channel of pixel 0, ldy = halfs between consecutive pixels of that buffer (the network's torch.cat of convolution outputs
+ *       becomes free) -- and optionally adding a residual tensor (d_res, row stride ldr; NULL for none) to the rounded result the
+ *       way two float16 tensors are added (the bottlenecks' x + cv2(cv1(x))). */
+int bf_conv2d_nhwc_f16_into_device(const void *d_x, const void *d_w, const float *d_bias, void *d_y, int ldy, const void *d_res, int ldr, int batch, int h,
+                                   int w, int c, int n, int kh, int kw, int stride, int pad, int silu, void *stream);
 int bf_nms_device(const float *d_boxes, const float *d_scores, const int *d_cls, const int *d_counts, int batch, int k, float iou_thres, int max_det,
                   unsigned long long *d_mask, float *d_out, int *d_out_count, void *stream);
 

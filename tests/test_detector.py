@@ -221,3 +221,30 @@ def test_gpu_detector_backends_agree(native):
     a, na = Detector(conv_backend="miopen").detect(frames, conf_thres=0.001)
     b, nb = Detector(conv_backend="hip").detect(frames, conf_thres=0.001)
     assert a.shape == b.shape and torch.equal(na > 0, nb > 0)
+
+
+@pytest.mark.gpu
+def test_gpu_hip_convolution_into_a_slice_with_residual(native):
+    """The C3 block's use: one convolution writes the upper channel half of the concatenation buffer, another the lower half with the
+    bottleneck's residual added -- equal to torch.cat((x + silu(conv_a(x)), silu(conv_b(x))), 1) computed from the same kernel's
+    plain outputs (the add as torch adds two float16 tensors), bit for bit; untouched channels stay untouched."""
+    import torch
+    from image_detection.model import yolov5s
+    g = torch.Generator(device="cpu").manual_seed(7)
+    B, C, H, W = 2, 64, 24, 20
+    convs = []
+    for k in (3, 1):
+        c = torch.nn.Conv2d(C, C, k, 1, k // 2, bias=True)
+        with torch.no_grad():
+            c.weight.copy_(torch.randn(c.weight.shape, generator=g) / (C * k * k) ** 0.5)
+            c.bias.copy_(torch.randn(c.bias.shape, generator=g) * 0.5)
+        convs.append(yolov5s.HipConv(c.cuda().half(), True))
+    x = (torch.randn((B, C, H, W), generator=g) * 1.5).cuda().half().contiguous(memory_format=torch.channels_last)
+    plain_a, plain_b = convs[0](x), convs[1](x)
+    buf = torch.full((B, 2 * C + 8, H, W), 7.0, dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+    ra = convs[0](x, out=buf[:, :C], residual=x)
+    rb = convs[1](x, out=buf[:, C:2 * C])
+    assert ra.data_ptr() == buf.data_ptr() and rb.data_ptr() == buf[:, C:].data_ptr()
+    assert torch.equal(buf[:, :C], x + plain_a) and torch.equal(buf[:, C:2 * C], plain_b) and bool((buf[:, 2 * C:] == 7.0).all())
+    with pytest.raises(Exception):
+        convs[0](x, out=buf[:, :C].permute(0, 1, 3, 2))

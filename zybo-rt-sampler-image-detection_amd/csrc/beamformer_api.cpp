@@ -1160,22 +1160,36 @@ int bf_topk_candidates_device(const float* d_scores, const float* d_boxes, const
 
 int bf_conv2d_weight_row(int kh, int kw, int c) { return kh > 0 && kw > 0 && c > 0 ? (kh * kw * c + 31) / 32 * 32 : -1; }
 
-int bf_conv2d_nhwc_f16_device(const void* d_x, const void* d_w, const float* d_bias, void* d_y, int batch, int h, int w, int c, int n, int kh, int kw, int stride,
-                              int pad, int silu, void* stream)
+static int conv2d_checked(const char* who, const void* d_x, const void* d_w, const float* d_bias, void* d_y, int batch, int h, int w, int c, int n, int kh, int kw,
+                          int stride, int pad, int silu, int ldy, const void* d_res, int ldr, void* stream)
 {
     std::lock_guard<std::mutex> lock(S().mu);
-    if (!d_x || !d_w || !d_y) { set_error("bf_conv2d_nhwc_f16_device: null pointer"); return -1; }
+    if (!d_x || !d_w || !d_y) { set_error("%s: null pointer", who); return -1; }
     if (batch < 1 || h < 1 || w < 1 || n < 1 || kh < 1 || kw < 1 || stride < 1 || pad < 0 || h + 2 * pad < kh || w + 2 * pad < kw) {
-        set_error("bf_conv2d_nhwc_f16_device: batch %d, %d x %d, window %d x %d, stride %d, pad %d", batch, h, w, kh, kw, stride, pad);
+        set_error("%s: batch %d, %d x %d, window %d x %d, stride %d, pad %d", who, batch, h, w, kh, kw, stride, pad);
         return -1;
     }
     if (c < 4 || (c & (c - 1)) != 0 || ((kw * c) & 7) != 0 || (c == 4 && ((stride & 1) || (pad & 1) || (w & 1)))) {
-        set_error("bf_conv2d_nhwc_f16_device: %d input channels, window width %d, stride %d, pad %d, width %d: channels must be a power of two >= 4 with "
-                  "kw * c a multiple of 8; 4 channels need even stride, pad and width", c, kw, stride, pad, w);
+        set_error("%s: %d input channels, window width %d, stride %d, pad %d, width %d: channels must be a power of two >= 4 with "
+                  "kw * c a multiple of 8; 4 channels need even stride, pad and width", who, c, kw, stride, pad, w);
         return -1;
     }
+    if (ldy < n || (d_res && ldr < n)) { set_error("%s: row strides %d / %d under %d output channels", who, ldy, ldr, n); return -1; }
     if (!ensure_device()) return -1;
-    return HIP_OK(bf::launch_conv2d_nhwc_f16(d_x, d_w, d_bias, d_y, batch, h, w, c, n, kh, kw, stride, pad, silu, reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
+    return HIP_OK(bf::launch_conv2d_nhwc_f16(d_x, d_w, d_bias, d_y, batch, h, w, c, n, kh, kw, stride, pad, silu, ldy, d_res, ldr,
+                                             reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
+}
+
+int bf_conv2d_nhwc_f16_device(const void* d_x, const void* d_w, const float* d_bias, void* d_y, int batch, int h, int w, int c, int n, int kh, int kw, int stride,
+                              int pad, int silu, void* stream)
+{
+    return conv2d_checked("bf_conv2d_nhwc_f16_device", d_x, d_w, d_bias, d_y, batch, h, w, c, n, kh, kw, stride, pad, silu, n, nullptr, 0, stream);
+}
+
+int bf_conv2d_nhwc_f16_into_device(const void* d_x, const void* d_w, const float* d_bias, void* d_y, int ldy, const void* d_res, int ldr, int batch, int h, int w,
+                                   int c, int n, int kh, int kw, int stride, int pad, int silu, void* stream)
+{
+    return conv2d_checked("bf_conv2d_nhwc_f16_into_device", d_x, d_w, d_bias, d_y, batch, h, w, c, n, kh, kw, stride, pad, silu, ldy, d_res, ldr, stream);
 }
 
 int bf_nms_device(const float* d_boxes, const float* d_scores, const int* d_cls, const int* d_counts, int batch, int k, float iou_thres, int max_det,

@@ -17,7 +17,9 @@
 //     ahead) -> LDS; rows are padded to 80 bytes, which spreads a wave's 16-byte fragment reads over all banks;
 //   * a wave owns 32 pixels x 64 channels: per 16-deep step one A fragment and two B fragments (ds_read_b128) feed two MFMAs;
 //   * the epilogue adds the bias, applies SiLU (x / (1 + exp(-x))), rounds to f16 and transposes the tile through LDS so that every
-//     thread stores 16 contiguous bytes of a pixel's channels (the 1x1 layers are bound by these stores).
+//     thread stores 16 contiguous bytes of a pixel's channels (the 1x1 layers are bound by these stores).  The output may be a
+//     channel slice of a wider NHWC buffer (row stride ldy: the network's concatenations cost nothing) and a residual tensor may be
+//     added to the rounded result (the bottlenecks' x + cv2(cv1(x)), added like torch adds two f16 tensors: in f32, rounded once).
 // Parity: tests/test_detector.py compares against torch's fp32 convolution of the same f16 operands.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -36,6 +38,9 @@ constexpr int kBM = 128, kBN = 64, kBK = 32, kRow = kBK + 8;   // halfs per LDS 
 
 struct ConvArgs {
     int B, H, W, C, Ho, Wo, N, KH, KW, stride, pad, act;
+    int ldy, ldr;         // halfs between consecutive pixels of the output / the residual
+    int wide;
+    const _Float16* res;  // optional residual, [M][ldr]
     int c_shift;          // log2(C)
     long long M;          // B * Ho * Wo
 };
@@ -136,18 +141,25 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const _Float16* __restr
         }
     }
     __syncthreads();
-    const bool wide = (a.N & 7) == 0;                          // 16-byte stores need 16-byte rows
+    const bool wide = a.wide != 0;                             // 16-byte stores need 16-byte rows and bases (launch_conv2d_nhwc_f16)
 #pragma unroll
     for (int j = 0; j < (kBM * kBN / 8) / 256; ++j) {
         const int id = tid + 256 * j, row = id >> 3, cc = (id & 7) * 8;
         const long long m = m0 + row;
         if (m >= a.M || n0 + cc >= a.N) continue;
         const _Float16* src = &Cs[row * kCRow + cc];
-        _Float16* dst = y + (size_t)m * a.N + n0 + cc;
+        _Float16* dst = y + (size_t)m * a.ldy + n0 + cc;
         if (wide) {
-            *reinterpret_cast<half8*>(dst) = *reinterpret_cast<const half8*>(src);
+            half8 v = *reinterpret_cast<const half8*>(src);
+            if (a.res) {
+                const half8 rv = *reinterpret_cast<const half8*>(a.res + (size_t)m * a.ldr + n0 + cc);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (_Float16)((float)v[e] + (float)rv[e]);
+            }
+            *reinterpret_cast<half8*>(dst) = v;
         } else {
-            for (int e = 0; e < 8 && n0 + cc + e < a.N; ++e) dst[e] = src[e];
+            for (int e = 0; e < 8 && n0 + cc + e < a.N; ++e)
+                dst[e] = a.res ? (_Float16)((float)src[e] + (float)a.res[(size_t)m * a.ldr + n0 + cc + e]) : src[e];
         }
     }
 }
@@ -155,8 +167,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const _Float16* __restr
 }  // namespace
 
 hipError_t launch_conv2d_nhwc_f16(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C, int N, int KH, int KW, int stride,
-                                  int pad, int act, hipStream_t stream)
+                                  int pad, int act, int ldy, const void* res, int ldr, hipStream_t stream)
 {
+    if (ldy < N || (res && ldr < N)) return hipErrorInvalidValue;
     if (B <= 0 || H <= 0 || W <= 0 || N <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return hipErrorInvalidValue;
     if (C < 4 || (C & (C - 1)) != 0 || ((KW * C) & 7) != 0) return hipErrorInvalidValue;       // whole 16-byte chunks per window row
     // C = 4: a chunk is two pixels, which must leave the image together -- even window starts, even width
@@ -166,6 +179,9 @@ hipError_t launch_conv2d_nhwc_f16(const void* x, const void* w, const float* bia
     a.Ho = (H + 2 * pad - KH) / stride + 1;
     a.Wo = (W + 2 * pad - KW) / stride + 1;
     if (a.Ho <= 0 || a.Wo <= 0) return hipErrorInvalidValue;
+    a.ldy = ldy; a.ldr = ldr; a.res = static_cast<const _Float16*>(res);
+    a.wide = ((N & 7) == 0 && (ldy & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+              (!res || ((ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0))) ? 1 : 0;
     a.c_shift = 0;
     while ((1 << a.c_shift) < C) ++a.c_shift;
     a.M = (long long)B * a.Ho * a.Wo;

@@ -132,8 +132,9 @@ hipError_t read_phase_stamps(unsigned long long* out16, bool clear);
 hipError_t launch_yolo_decode(const void* const raw[3], const int hs[3], const int ws[3], const int strides[3], const float* anchors,
                               int batch, int nc, int is_half, float conf_thres, float* d_boxes, float* d_scores, int* d_cls, hipStream_t stream);
 // Convolution + bias + optional SiLU, NHWC f16 in / out, weights [N][KH][KW][C] f16 (conv_kernels.hip).  C a power of two >= 8, KW * C a multiple of 32.
+// ldy: halfs between consecutive output pixels (>= N: the output may be a channel slice of a wider buffer); res / ldr: optional residual added to the result.
 hipError_t launch_conv2d_nhwc_f16(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C, int N, int KH, int KW, int stride,
-                                  int pad, int act, hipStream_t stream);
+                                  int pad, int act, int ldy, const void* res, int ldr, hipStream_t stream);
 hipError_t launch_topk_candidates(const float* d_scores, const float* d_boxes, const int* d_cls, int batch, int total, int K, float* d_top_scores,
                                   float* d_top_boxes, int* d_top_cls, int* d_counts, hipStream_t stream);
 hipError_t launch_nms(const float* d_boxes, const float* d_scores, const int* d_cls, const int* d_counts, int batch, int K, float iou_thres,

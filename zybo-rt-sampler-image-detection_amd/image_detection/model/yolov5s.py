@@ -21,8 +21,9 @@ class Conv(nn.Module):
         self.bn = nn.BatchNorm2d(c2, eps=1e-3, momentum=0.03)
         self.act = nn.SiLU(inplace=True)
 
-    def forward(self, x):
-        return self.act(self.bn(self.conv(x)))
+    def forward(self, x, **into):
+        """`into` (HipConv only): out= a channel slice of a wider channels_last buffer to write to, residual= a tensor to add."""
+        return self.act(self.bn(self.conv(x, **into))) if into else self.act(self.bn(self.conv(x)))
 
     def fuse(self):
         """Fold the BatchNorm into the convolution (inference)."""
@@ -39,7 +40,9 @@ class Bottleneck(nn.Module):
         self.cv1, self.cv2 = Conv(c1, c2, 1), Conv(c2, c2, 3)
         self.add = shortcut and c1 == c2
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        if isinstance(self.cv2.conv, HipConv):            # the add (and the caller's concatenation) happen in cv2's epilogue
+            return self.cv2(self.cv1(x), out=out, residual=x if self.add else None)
         y = self.cv2(self.cv1(x))
         return x + y if self.add else y
 
@@ -52,6 +55,17 @@ class C3(nn.Module):
         self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut) for _ in range(n)))
 
     def forward(self, x):
+        if isinstance(self.cv3.conv, HipConv):
+            # both halves of the concatenation are convolution outputs: they are written straight into its buffer
+            b, _, h, w = x.shape
+            c_ = self.cv1.conv.n
+            buf = torch.empty((b, 2 * c_, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            self.cv2(x, out=buf[:, c_:])
+            y = self.cv1(x)
+            for blk in self.m[:-1]:
+                y = blk(y)
+            self.m[-1](y, out=buf[:, :c_])
+            return self.cv3(buf)
         return self.cv3(torch.cat((self.m(self.cv1(x)), self.cv2(x)), 1))
 
 
@@ -127,7 +141,9 @@ class HipConv(nn.Module):
         self.c, self.cp, self.n, self.kh, self.kw = c, cp, n, kh, kw
         self.stride, self.pad, self.silu = int(conv.stride[0]), int(conv.padding[0]), 1 if silu else 0
 
-    def forward(self, x):
+    def forward(self, x, out=None, residual=None):
+        """out: None (a new channels_last tensor) or a channel slice [B, n, Ho, Wo] of a channels_last buffer; residual: None or a
+        channels_last [B, n, Ho, Wo] tensor (or slice) added to the rounded result."""
         from lib import _native as nat
         b, c, h, w = (int(v) for v in x.shape)
         if x.dtype != torch.float16 or c != self.c:
@@ -140,10 +156,16 @@ class HipConv(nn.Module):
         elif not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
         ho, wo = (h + 2 * self.pad - self.kh) // self.stride + 1, (w + 2 * self.pad - self.kw) // self.stride + 1
-        y = torch.empty((b, self.n, ho, wo), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
-        if nat.lib.bf_conv2d_nhwc_f16_device(x.data_ptr(), self.wp.data_ptr(), None if self.bias is None else self.bias.data_ptr(), y.data_ptr(),
-                                             b, h, w, self.cp, self.n, self.kh, self.kw, self.stride, self.pad, self.silu,
-                                             torch.cuda.current_stream().cuda_stream) != 0:
+        y = torch.empty((b, self.n, ho, wo), dtype=torch.float16, device=x.device, memory_format=torch.channels_last) if out is None else out
+        for t in (y, residual):
+            # an NHWC buffer or a channel slice of one: channels adjacent, pixels in (b, h, w) order at one pitch
+            if t is not None and (tuple(t.shape) != (b, self.n, ho, wo) or t.dtype != torch.float16 or t.stride(1) != 1 or t.stride(2) != wo * t.stride(3) or
+                                  t.stride(0) != ho * wo * t.stride(3)):
+                raise nat.BeamformerError("HipConv: out / residual must be [%d, %d, %d, %d] float16 channel slices of channels_last buffers" % (b, self.n, ho, wo))
+        if nat.lib.bf_conv2d_nhwc_f16_into_device(x.data_ptr(), self.wp.data_ptr(), None if self.bias is None else self.bias.data_ptr(), y.data_ptr(),
+                                                  int(y.stride(3)), None if residual is None else residual.data_ptr(),
+                                                  0 if residual is None else int(residual.stride(3)), b, h, w, self.cp, self.n, self.kh, self.kw,
+                                                  self.stride, self.pad, self.silu, torch.cuda.current_stream().cuda_stream) != 0:
             nat.check()
         return y
 
