@@ -1679,7 +1679,13 @@ __device__ __forceinline__ void pair_steps(f32x2 (&acc)[8][2][2], Quad& S0, Quad
     if constexpr (ALGO == ALGO_PAD) {
         // pad_and_sum.c:41-47   out[k] += s[k - p]
         if constexpr (Q == 0) {
-            asm volatile(BF_P_ADDR(eb) BF_P_PAD_READ BF_P_PAD_STEP(0, 1) BF_P_CHECK(1, eb, ec) BF_P_PAD_STEP(2, 3)
+            // (step 0: each frame's adds wait only for that frame's two reads -- LDS returns in order)
+            asm volatile(BF_P_ADDR(eb)
+                         "ds_read_b64 %[s0l], %[ad] offset:0\n\tds_read_b64 %[s0h], %[ad] offset:8\n\t"
+                         "ds_read_b64 %[s1l], %[ad] offset:%[f0]\n\tds_read_b64 %[s1h], %[ad] offset:%[f8]\n\ts_waitcnt lgkmcnt(2)\n\t"
+                         "v_pk_add_f32 %[a00], %[a00], %[s0l]\n\tv_pk_add_f32 %[a01], %[a01], %[s0h]\n\ts_waitcnt lgkmcnt(0)\n\t"
+                         "v_pk_add_f32 %[a10], %[a10], %[s1l]\n\tv_pk_add_f32 %[a11], %[a11], %[s1h]\n\t"
+                         BF_P_CHECK(1, eb, ec) BF_P_PAD_STEP(2, 3)
                          ".subsection 1\n" BF_P_STUB(1, ec, BF_P_PAD_READ) "\t.subsection 0"
                          : BF_P_ACC(0, JA, 0), BF_P_ACC(1, JA, 1), BF_P_ACC(2, JB, 0), BF_P_ACC(3, JB, 1), [s0l] "+v"(S0.lo), [s0h] "+v"(S0.hi),
                            [s1l] "+v"(S1.lo), [s1h] "+v"(S1.hi), [ad] "=&v"(ad)
@@ -1717,6 +1723,28 @@ __device__ __forceinline__ void pair_steps(f32x2 (&acc)[8][2][2], Quad& S0, Quad
 #undef BF_P_LERP_OUTS
 #undef BF_P_LERP_IMMS
     }
+}
+
+// pad, direction steps 2..7 of a mic for both frames as ONE statement (between two statements the hazard recogniser puts an s_nop:
+// three issue slots per mic with one statement per pair of steps).
+__device__ __forceinline__ void pair_pad_rest(f32x2 (&acc)[8][2][2], Quad& S0, Quad& S1, const int (&e)[8], int lbase)
+{
+    using G = PairGeo<ALGO_PAD>;
+    int ad;
+#define BF_P_ACC2(n, j) [a##n##0] "+v"(acc[j][0][0]), [a##n##1] "+v"(acc[j][0][1]), [b##n##0] "+v"(acc[j][1][0]), [b##n##1] "+v"(acc[j][1][1])
+#define BF_P_PAD1(n) "v_pk_add_f32 %[a" #n "0], %[a" #n "0], %[s0l]\n\tv_pk_add_f32 %[a" #n "1], %[a" #n "1], %[s0h]\n\t" \
+                     "v_pk_add_f32 %[b" #n "0], %[b" #n "0], %[s1l]\n\tv_pk_add_f32 %[b" #n "1], %[b" #n "1], %[s1h]\n\t"
+    asm volatile(BF_P_CHECK(2, e1, e2) BF_P_PAD1(2) BF_P_CHECK(3, e2, e3) BF_P_PAD1(3) BF_P_CHECK(4, e3, e4) BF_P_PAD1(4)
+                 BF_P_CHECK(5, e4, e5) BF_P_PAD1(5) BF_P_CHECK(6, e5, e6) BF_P_PAD1(6) BF_P_CHECK(7, e6, e7) BF_P_PAD1(7)
+                 ".subsection 1\n" BF_P_STUB(2, e2, BF_P_PAD_READ) BF_P_STUB(3, e3, BF_P_PAD_READ) BF_P_STUB(4, e4, BF_P_PAD_READ)
+                 BF_P_STUB(5, e5, BF_P_PAD_READ) BF_P_STUB(6, e6, BF_P_PAD_READ) BF_P_STUB(7, e7, BF_P_PAD_READ) "\t.subsection 0"
+                 : BF_P_ACC2(2, 2), BF_P_ACC2(3, 3), BF_P_ACC2(4, 4), BF_P_ACC2(5, 5), BF_P_ACC2(6, 6), BF_P_ACC2(7, 7),
+                   [s0l] "+v"(S0.lo), [s0h] "+v"(S0.hi), [s1l] "+v"(S1.lo), [s1h] "+v"(S1.hi), [ad] "=&v"(ad)
+                 : [e1] "s"(e[1]), [e2] "s"(e[2]), [e3] "s"(e[3]), [e4] "s"(e[4]), [e5] "s"(e[5]), [e6] "s"(e[6]), [e7] "s"(e[7]), [lb] "v"(lbase),
+                   [f0] "n"(G::kFoff), [f8] "n"(G::kFoff + 8)
+                 : "scc");
+#undef BF_P_ACC2
+#undef BF_P_PAD1
 }
 
 // Profiling build only (-DBF_STAMPS, scripts/dev/phase_stamps.py): every wave sums the time it spends in each phase of
@@ -1846,6 +1874,10 @@ __global__ void __launch_bounds__(1024, 4) das_pair_kernel(BF_TABLE_PARAMS, KArg
                     const Entries& cur = E[K];
                     pair_steps<ALGO, 0>(acc, S0, D0, S1, D1, cur.e[0], cur.e[0], cur.e[1], cur.hp[0], lb);
                     request(E[K2], m + 2);      // after the first statement's wait, so that it does not sit on these loads
+                    if constexpr (ALGO == ALGO_PAD) {
+                        pair_pad_rest(acc, S0, S1, cur.e, lb);
+                        return;
+                    }
                     pair_steps<ALGO, 1>(acc, S0, D0, S1, D1, cur.e[1], cur.e[2], cur.e[3], cur.hp[1], lb);
                     pair_steps<ALGO, 2>(acc, S0, D0, S1, D1, cur.e[3], cur.e[4], cur.e[5], cur.hp[2], lb);
                     pair_steps<ALGO, 3>(acc, S0, D0, S1, D1, cur.e[5], cur.e[6], cur.e[7], cur.hp[3], lb);
