@@ -1687,8 +1687,9 @@ __device__ __forceinline__ void pair_steps(f32x2 (&acc)[8][2][2], Quad& S0, Quad
                          "v_pk_add_f32 %[a10], %[a10], %[s1l]\n\tv_pk_add_f32 %[a11], %[a11], %[s1h]\n\t"
                          BF_P_CHECK(1, eb, ec) BF_P_PAD_STEP(2, 3)
                          ".subsection 1\n" BF_P_STUB(1, ec, BF_P_PAD_READ) "\t.subsection 0"
-                         : BF_P_ACC(0, JA, 0), BF_P_ACC(1, JA, 1), BF_P_ACC(2, JB, 0), BF_P_ACC(3, JB, 1), [s0l] "+v"(S0.lo), [s0h] "+v"(S0.hi),
-                           [s1l] "+v"(S1.lo), [s1h] "+v"(S1.hi), [ad] "=&v"(ad)
+                         // (the quads are pure outputs here: as in-out operands they are carried around the mic loop -- and copied at its back-edge)
+                         : BF_P_ACC(0, JA, 0), BF_P_ACC(1, JA, 1), BF_P_ACC(2, JB, 0), BF_P_ACC(3, JB, 1), [s0l] "=&v"(S0.lo), [s0h] "=&v"(S0.hi),
+                           [s1l] "=&v"(S1.lo), [s1h] "=&v"(S1.hi), [ad] "=&v"(ad)
                          : [eb] "s"(eb), [ec] "s"(ec), [lb] "v"(lbase), [f0] "n"(G::kFoff), [f8] "n"(G::kFoff + 8) : "scc");
         } else {
             asm volatile(BF_P_CHECK(0, ea, eb) BF_P_PAD_STEP(0, 1) BF_P_CHECK(1, eb, ec) BF_P_PAD_STEP(2, 3)
