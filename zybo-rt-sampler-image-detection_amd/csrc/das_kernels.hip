@@ -822,8 +822,6 @@ struct Quad { f32x2 lo, hi; };
 #define BF_RELOAD_TAIL "s_waitcnt lgkmcnt(0)\n\ts_branch .Lback_%=\n\t.subsection 0"
 #define BF_S_OPS(sg) [s##sg##l] "+v"(S[sg].lo), [s##sg##h] "+v"(S[sg].hi)
 #define BF_D_OPS(sg) [d##sg##l] "+v"(D[sg].lo), [d##sg##h] "+v"(D[sg].hi)
-#define BF_S_OUT(sg) [s##sg##l] "=&v"(S[sg].lo), [s##sg##h] "=&v"(S[sg].hi)
-#define BF_D_OUT(sg) [d##sg##l] "=&v"(D[sg].lo), [d##sg##h] "=&v"(D[sg].hi)
 
 template <int NSEG, bool LERP>
 __device__ __forceinline__ void reload_quads(Quad (&S)[NSEG], Quad (&D)[NSEG], int e, int ep, int lbase, int d_off)
@@ -912,66 +910,12 @@ __device__ __forceinline__ void await_quads(Quad (&S)[NSEG], Quad (&D)[NSEG])
         asm volatile("" : BF_S_OPS(0), BF_D_OPS(0), BF_S_OPS(1), BF_D_OPS(1), BF_S_OPS(2), BF_D_OPS(2), BF_S_OPS(3), BF_D_OPS(3));
     }
 }
-// The same two helpers for the CONFLICT-FREE lane mapping of das_long_kernel: lane l owns the sample pairs 2l, 2l+1 and
-// 128 + 2l, 128 + 2l + 1 of every 256-sample segment, so that each ds_read_b64 covers 512 contiguous bytes (64 banks, no lane
-// pair on the same bank; with the 16-byte lane stride above every ds_read_b64 is a two-way conflict: SQ_LDS_BANK_CONFLICT).
-// Segment s: low pair at byte 1024 s + 8 l, high pair 512 bytes further.
-template <int NSEG, bool LERP>
-__device__ __forceinline__ void reload_quads_cf(Quad (&S)[NSEG], Quad (&D)[NSEG], int e, int ep, int lbase, int d_off)
-{
-    int ad, ad2;
-    static_assert(NSEG == 2 || NSEG == 4, "long rows: 2 or 4 segments");
-    if constexpr (NSEG == 2 && !LERP) {
-        asm volatile(BF_RELOAD_HEAD "v_add_u32 %[ad], %[e], %[lb]\n\t" BF_RD(0, 0, 512) BF_RD(1, 1024, 1536) BF_RELOAD_TAIL
-                     : BF_S_OPS(0), BF_S_OPS(1), [ad] "=&v"(ad) : [e] "s"(e), [ep] "s"(ep), [lb] "v"(lbase) : "scc");
-    } else if constexpr (NSEG == 2 && LERP) {
-        asm volatile(BF_RELOAD_HEAD "v_add_u32 %[ad], %[e], %[lb]\n\tv_add_u32 %[ad2], %[ad], %[doff]\n\t" BF_RD(0, 0, 512)
-                         BF_RDD(0, 0, 512) BF_RD(1, 1024, 1536) BF_RDD(1, 1024, 1536) BF_RELOAD_TAIL
-                     : BF_S_OPS(0), BF_D_OPS(0), BF_S_OPS(1), BF_D_OPS(1), [ad] "=&v"(ad), [ad2] "=&v"(ad2)
-                     : [e] "s"(e), [ep] "s"(ep), [lb] "v"(lbase), [doff] "s"(d_off) : "scc");
-    } else if constexpr (NSEG == 4 && !LERP) {
-        asm volatile(BF_RELOAD_HEAD "v_add_u32 %[ad], %[e], %[lb]\n\t" BF_RD(0, 0, 512) BF_RD(1, 1024, 1536) BF_RD(2, 2048, 2560)
-                         BF_RD(3, 3072, 3584) BF_RELOAD_TAIL
-                     : BF_S_OPS(0), BF_S_OPS(1), BF_S_OPS(2), BF_S_OPS(3), [ad] "=&v"(ad) : [e] "s"(e), [ep] "s"(ep), [lb] "v"(lbase) : "scc");
-    } else {
-        asm volatile(BF_RELOAD_HEAD "v_add_u32 %[ad], %[e], %[lb]\n\tv_add_u32 %[ad2], %[ad], %[doff]\n\t" BF_RD(0, 0, 512)
-                         BF_RDD(0, 0, 512) BF_RD(1, 1024, 1536) BF_RDD(1, 1024, 1536) BF_RD(2, 2048, 2560) BF_RDD(2, 2048, 2560) BF_RD(3, 3072, 3584) BF_RDD(3, 3072, 3584)
-                     BF_RELOAD_TAIL
-                     : BF_S_OPS(0), BF_D_OPS(0), BF_S_OPS(1), BF_D_OPS(1), BF_S_OPS(2), BF_D_OPS(2), BF_S_OPS(3), BF_D_OPS(3), [ad] "=&v"(ad), [ad2] "=&v"(ad2)
-                     : [e] "s"(e), [ep] "s"(ep), [lb] "v"(lbase), [doff] "s"(d_off) : "scc");
-    }
-}
-// (issue and wait in ONE statement: a mic's first quads, read in place; pure outputs -- as in-out operands the compiler has to give
-// them a defined value first: 16 v_mov per mic in the 4-segment lerp sweep, a fifth of its vector instructions)
-template <int NSEG, bool LERP>
-__device__ __forceinline__ void load_quads_cf(Quad (&S)[NSEG], Quad (&D)[NSEG], int e, int lbase, int d_off)
-{
-    int ad, ad2;
-    if constexpr (NSEG == 2 && !LERP) {
-        asm volatile("v_add_u32 %[ad], %[e], %[lb]\n\t" BF_RD(0, 0, 512) BF_RD(1, 1024, 1536) "s_waitcnt lgkmcnt(0)"
-                     : BF_S_OUT(0), BF_S_OUT(1), [ad] "=&v"(ad) : [e] "s"(e), [lb] "v"(lbase));
-    } else if constexpr (NSEG == 2 && LERP) {
-        asm volatile("v_add_u32 %[ad], %[e], %[lb]\n\tv_add_u32 %[ad2], %[ad], %[doff]\n\t" BF_RD(0, 0, 512) BF_RDD(0, 0, 512) BF_RD(1, 1024, 1536)
-                         BF_RDD(1, 1024, 1536) "s_waitcnt lgkmcnt(0)"
-                     : BF_S_OUT(0), BF_D_OUT(0), BF_S_OUT(1), BF_D_OUT(1), [ad] "=&v"(ad), [ad2] "=&v"(ad2) : [e] "s"(e), [lb] "v"(lbase), [doff] "s"(d_off));
-    } else if constexpr (NSEG == 4 && !LERP) {
-        asm volatile("v_add_u32 %[ad], %[e], %[lb]\n\t" BF_RD(0, 0, 512) BF_RD(1, 1024, 1536) BF_RD(2, 2048, 2560) BF_RD(3, 3072, 3584) "s_waitcnt lgkmcnt(0)"
-                     : BF_S_OUT(0), BF_S_OUT(1), BF_S_OUT(2), BF_S_OUT(3), [ad] "=&v"(ad) : [e] "s"(e), [lb] "v"(lbase));
-    } else {
-        asm volatile("v_add_u32 %[ad], %[e], %[lb]\n\tv_add_u32 %[ad2], %[ad], %[doff]\n\t" BF_RD(0, 0, 512) BF_RDD(0, 0, 512) BF_RD(1, 1024, 1536)
-                         BF_RDD(1, 1024, 1536) BF_RD(2, 2048, 2560) BF_RDD(2, 2048, 2560) BF_RD(3, 3072, 3584) BF_RDD(3, 3072, 3584) "s_waitcnt lgkmcnt(0)"
-                     : BF_S_OUT(0), BF_D_OUT(0), BF_S_OUT(1), BF_D_OUT(1), BF_S_OUT(2), BF_D_OUT(2), BF_S_OUT(3), BF_D_OUT(3), [ad] "=&v"(ad), [ad2] "=&v"(ad2)
-                     : [e] "s"(e), [lb] "v"(lbase), [doff] "s"(d_off));
-    }
-}
 #undef BF_RD
 #undef BF_RELOAD_HEAD
 #undef BF_RELOAD_TAIL
 #undef BF_RDD
 #undef BF_S_OPS
 #undef BF_D_OPS
-#undef BF_S_OUT
-#undef BF_D_OUT
 
 // acc += quad (pad) / acc += fma(h, D, S) (lerp) on the two register pairs of a segment.  asm so that it stays between
 // the reloads in program order (a C++ expression may be sunk below the next reload at the price of register copies).
@@ -2757,6 +2701,85 @@ __device__ __forceinline__ void long_lerp_rest(f32x2 (&acc)[Geo<NSEG>::kDw][NSEG
 #undef BF_L_OUT2
 #undef BF_L_OUT4
 }
+// ---- pad on long rows, the same way: quads (8-byte pairs, no differences) in hard-wired v[92:107], address v90; S1 / continuation /
+// S2 statements, counted waits in a mic's first step, the next mic's reads behind the last step's segments.
+// pad_and_sum.c:41-47   out[k] += s[k - p]
+#define BF_LP_SEG(n, sg, LO, HI) "v_pk_add_f32 %[a" #n #sg "0], %[a" #n #sg "0], v[" LO "]\n\tv_pk_add_f32 %[a" #n #sg "1], %[a" #n #sg "1], v[" HI "]\n\t"
+#define BF_LP_RD(q, off) "ds_read_b64 v[" q "], v90 offset:" #off "\n\t"
+#define BF_LP_STEP2(n) BF_LP_SEG(n, 0, "92:93", "94:95") BF_LP_SEG(n, 1, "96:97", "98:99")
+#define BF_LP_STEP4(n) BF_LP_STEP2(n) BF_LP_SEG(n, 2, "100:101", "102:103") BF_LP_SEG(n, 3, "104:105", "106:107")
+#define BF_LP_STEP2_W(n) "s_waitcnt lgkmcnt(2)\n\t" BF_LP_SEG(n, 0, "92:93", "94:95") "s_waitcnt lgkmcnt(0)\n\t" BF_LP_SEG(n, 1, "96:97", "98:99")
+#define BF_LP_STEP4_W(n) "s_waitcnt lgkmcnt(6)\n\t" BF_LP_SEG(n, 0, "92:93", "94:95") "s_waitcnt lgkmcnt(4)\n\t" BF_LP_SEG(n, 1, "96:97", "98:99") \
+                         "s_waitcnt lgkmcnt(2)\n\t" BF_LP_SEG(n, 2, "100:101", "102:103") "s_waitcnt lgkmcnt(0)\n\t" BF_LP_SEG(n, 3, "104:105", "106:107")
+#define BF_LP_STEP2_PF(n) BF_LP_SEG(n, 0, "92:93", "94:95") BF_LP_RD("92:93", 0) BF_LP_RD("94:95", 512) \
+                          BF_LP_SEG(n, 1, "96:97", "98:99") BF_LP_RD("96:97", 1024) BF_LP_RD("98:99", 1536)
+#define BF_LP_STEP4_PF(n) BF_LP_STEP2_PF(n) BF_LP_SEG(n, 2, "100:101", "102:103") BF_LP_RD("100:101", 2048) BF_LP_RD("102:103", 2560) \
+                          BF_LP_SEG(n, 3, "104:105", "106:107") BF_LP_RD("104:105", 3072) BF_LP_RD("106:107", 3584)
+#define BF_LP_READ2 BF_LP_RD("92:93", 0) BF_LP_RD("94:95", 512) BF_LP_RD("96:97", 1024) BF_LP_RD("98:99", 1536)
+#define BF_LP_READ4 BF_LP_READ2 BF_LP_RD("100:101", 2048) BF_LP_RD("102:103", 2560) BF_LP_RD("104:105", 3072) BF_LP_RD("106:107", 3584)
+#define BF_LP_CLOB "v90", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107"
+template <int NSEG>
+__device__ __forceinline__ void long_pad_first(f32x2 (&acc)[Geo<NSEG>::kDw][NSEG][2], int e0, int lbase)
+{
+    if constexpr (NSEG == 2) {
+        asm volatile("v_add_u32 v90, %[e0], %[lb]\n\t" BF_LP_READ2 BF_LP_STEP2_W(0) ";BF_S1_END 90 107" : BF_L_ACC2(0, 0) : [e0] "s"(e0), [lb] "v"(lbase) : BF_LP_CLOB);
+    } else {
+        asm volatile("v_add_u32 v90, %[e0], %[lb]\n\t" BF_LP_READ4 BF_LP_STEP4_W(0) ";BF_S1_END 90 107" : BF_L_ACC4(0, 0) : [e0] "s"(e0), [lb] "v"(lbase) : BF_LP_CLOB);
+    }
+}
+template <int NSEG>
+__device__ __forceinline__ void long_pad_cont(f32x2 (&acc)[Geo<NSEG>::kDw][NSEG][2])
+{
+    if constexpr (NSEG == 2) {
+        asm volatile(";BF_S2_BEGIN\n\t" BF_LP_STEP2_W(0) ";BF_S1_END 90 107" : BF_L_ACC2(0, 0) : : BF_LP_CLOB);
+    } else {
+        asm volatile(";BF_S2_BEGIN\n\t" BF_LP_STEP4_W(0) ";BF_S1_END 90 107" : BF_L_ACC4(0, 0) : : BF_LP_CLOB);
+    }
+}
+template <int NSEG, bool PF>
+__device__ __forceinline__ void long_pad_rest(f32x2 (&acc)[Geo<NSEG>::kDw][NSEG][2], const int (&e)[Geo<NSEG>::kDw], int lbase, int n0)
+{
+#define BF_LP_STUBS2 ".subsection 1\n" BF_L_STUB(1, e1, BF_LP_READ2) BF_L_STUB(2, e2, BF_LP_READ2) BF_L_STUB(3, e3, BF_LP_READ2) BF_L_STUB(4, e4, BF_LP_READ2) \
+                     BF_L_STUB(5, e5, BF_LP_READ2) BF_L_STUB(6, e6, BF_LP_READ2) BF_L_STUB(7, e7, BF_LP_READ2) "\t.subsection 0\n\t"
+#define BF_LP_STUBS4 ".subsection 1\n" BF_L_STUB(1, e1, BF_LP_READ4) BF_L_STUB(2, e2, BF_LP_READ4) BF_L_STUB(3, e3, BF_LP_READ4) "\t.subsection 0\n\t"
+#define BF_LP_BODY2 BF_L_CHECK(1, e0, e1) BF_LP_STEP2(1) BF_L_CHECK(2, e1, e2) BF_LP_STEP2(2) BF_L_CHECK(3, e2, e3) BF_LP_STEP2(3) BF_L_CHECK(4, e3, e4) BF_LP_STEP2(4) \
+                    BF_L_CHECK(5, e4, e5) BF_LP_STEP2(5) BF_L_CHECK(6, e5, e6) BF_LP_STEP2(6) BF_L_CHECK(7, e6, e7)
+#define BF_LP_BODY4 BF_L_CHECK(1, e0, e1) BF_LP_STEP4(1) BF_L_CHECK(2, e1, e2) BF_LP_STEP4(2) BF_L_CHECK(3, e2, e3)
+#define BF_LP_IN2 [e0] "s"(e[0]), [e1] "s"(e[1]), [e2] "s"(e[2]), [e3] "s"(e[3]), [e4] "s"(e[4]), [e5] "s"(e[5]), [e6] "s"(e[6]), [e7] "s"(e[7]), [lb] "v"(lbase)
+#define BF_LP_IN4 [e0] "s"(e[0]), [e1] "s"(e[1]), [e2] "s"(e[2]), [e3] "s"(e[3]), [lb] "v"(lbase)
+#define BF_LP_OUT2 BF_L_ACC2(1, 1), BF_L_ACC2(2, 2), BF_L_ACC2(3, 3), BF_L_ACC2(4, 4), BF_L_ACC2(5, 5), BF_L_ACC2(6, 6), BF_L_ACC2(7, 7)
+#define BF_LP_OUT4 BF_L_ACC4(1, 1), BF_L_ACC4(2, 2), BF_L_ACC4(3, 3)
+    if constexpr (NSEG == 2 && !PF) {
+        asm volatile(";BF_S2_BEGIN\n\t" BF_LP_BODY2 BF_LP_STEP2(7) BF_LP_STUBS2 : BF_LP_OUT2 : BF_LP_IN2 : "scc", BF_LP_CLOB);
+    } else if constexpr (NSEG == 2 && PF) {
+        asm volatile(";BF_S2_BEGIN\n\t" BF_LP_BODY2 BF_LP_STUBS2 "v_add_u32 v90, %[n0], %[lb]\n\t" BF_LP_STEP2_PF(7) ";BF_S1_END 90 107"
+                     : BF_LP_OUT2 : BF_LP_IN2, [n0] "s"(n0) : "scc", BF_LP_CLOB);
+    } else if constexpr (NSEG == 4 && !PF) {
+        asm volatile(";BF_S2_BEGIN\n\t" BF_LP_BODY4 BF_LP_STEP4(3) BF_LP_STUBS4 : BF_LP_OUT4 : BF_LP_IN4 : "scc", BF_LP_CLOB);
+    } else {
+        asm volatile(";BF_S2_BEGIN\n\t" BF_LP_BODY4 BF_LP_STUBS4 "v_add_u32 v90, %[n0], %[lb]\n\t" BF_LP_STEP4_PF(3) ";BF_S1_END 90 107"
+                     : BF_LP_OUT4 : BF_LP_IN4, [n0] "s"(n0) : "scc", BF_LP_CLOB);
+    }
+#undef BF_LP_STUBS2
+#undef BF_LP_STUBS4
+#undef BF_LP_BODY2
+#undef BF_LP_BODY4
+#undef BF_LP_IN2
+#undef BF_LP_IN4
+#undef BF_LP_OUT2
+#undef BF_LP_OUT4
+}
+#undef BF_LP_SEG
+#undef BF_LP_RD
+#undef BF_LP_STEP2
+#undef BF_LP_STEP4
+#undef BF_LP_STEP2_W
+#undef BF_LP_STEP4_W
+#undef BF_LP_STEP2_PF
+#undef BF_LP_STEP4_PF
+#undef BF_LP_READ2
+#undef BF_LP_READ4
+#undef BF_LP_CLOB
 #undef BF_L_LO
 #undef BF_L_HI
 #undef BF_L_SEG
@@ -2895,7 +2918,6 @@ __global__ void __launch_bounds__(1024, 4) das_long_kernel(BF_TABLE_PARAMS, KArg
     };
 
     const int lb = (kLerp ? 16 : 8) * lane + (int)(unsigned)(size_t)((__attribute__((address_space(3))) char*)lds);
-    [[maybe_unused]] const int d_off = 0;
 
     for (int g0 = tile_begin; g0 < tile_end; g0 += kGroup) {
         f32x2 acc[DW][NSEG][2];
@@ -2941,9 +2963,6 @@ __global__ void __launch_bounds__(1024, 4) das_long_kernel(BF_TABLE_PARAMS, KArg
                 if (h + 2 < n_half) st = fetch_next();          // half h + 2
             }
             if (busy) {
-                Quad S[NSEG], Dq[NSEG];
-#pragma unroll
-                for (int sg = 0; sg < NSEG; ++sg) S[sg].lo = S[sg].hi = Dq[sg].lo = Dq[sg].hi = f32x2{0.0f, 0.0f};
                 auto mic = [&](int m, auto kc, auto pc) {
                     constexpr int K = decltype(kc)::value, K2 = (K + 2) % KE, POS = decltype(pc)::value;   // POS: the mic's place in its half
                     const Entries& cur = E[K];
@@ -2957,29 +2976,13 @@ __global__ void __launch_bounds__(1024, 4) das_long_kernel(BF_TABLE_PARAMS, KArg
                         request(E[K2], m + 2);
                         if constexpr (POS == HC - 1) long_lerp_rest<NSEG, false>(acc, cur.e, cur.hp, lb, 0);
                         else long_lerp_rest<NSEG, true>(acc, cur.e, cur.hp, lb, E[(K + 1) % KE].e[0]);
-                        return;
-                    }
-                    __builtin_amdgcn_s_waitcnt(0xC07F);         // this mic's entries (requested two mics ago) have landed
-                    load_quads_cf<NSEG, kLerp>(S, Dq, cur.e[0], lb, d_off);
-                    request(E[K2], m + 2);                      // after the reads' wait, so that it does not sit on these loads
-                    auto stepj = [&](auto jc) {
-                        constexpr int j = decltype(jc)::value;
-                        if constexpr (j > 0) reload_quads_cf<NSEG, kLerp>(S, Dq, cur.e[j], cur.e[j - 1], lb, d_off);
-#pragma unroll
-                        for (int sg = 0; sg < NSEG; ++sg) {
-                            if constexpr (ALGO == ALGO_PAD) add_quad(acc[j][sg], S[sg]);
-                            else lerp_quad<j & 1>(acc[j][sg], S[sg], Dq[sg], cur.hp[j / 2]);
-                        }
-                    };
-                    stepj(std::integral_constant<int, 0>{});
-                    stepj(std::integral_constant<int, 1>{});
-                    stepj(std::integral_constant<int, 2>{});
-                    stepj(std::integral_constant<int, 3>{});
-                    if constexpr (DW == 8) {
-                        stepj(std::integral_constant<int, 4>{});
-                        stepj(std::integral_constant<int, 5>{});
-                        stepj(std::integral_constant<int, 6>{});
-                        stepj(std::integral_constant<int, 7>{});
+                    } else {                                    // pad, the same structure
+                        if constexpr (POS == 0) long_pad_first<NSEG>(acc, cur.e[0], lb);
+                        else long_pad_cont<NSEG>(acc);
+                        __builtin_amdgcn_s_waitcnt(0xC07F);
+                        request(E[K2], m + 2);
+                        if constexpr (POS == HC - 1) long_pad_rest<NSEG, false>(acc, cur.e, lb, 0);
+                        else long_pad_rest<NSEG, true>(acc, cur.e, lb, E[(K + 1) % KE].e[0]);
                     }
                 };
                 using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
