@@ -34,7 +34,8 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
-constexpr int kBM = 128, kBN = 64, kBK = 32, kRow = kBK + 8;   // halfs per LDS row (80 bytes)
+constexpr int kBM = 128, kBK = 32, kRow = kBK + 8;   // halfs per LDS row (80 bytes)
+// kBN (template parameter): output channels per workgroup tile, 64 or -- for layers of up to 32 channels, the 6x6 stem among them -- 32
 
 struct ConvArgs {
     int B, H, W, C, Ho, Wo, N, KH, KW, stride, pad, act;
@@ -45,6 +46,7 @@ struct ConvArgs {
     long long M;          // B * Ho * Wo
 };
 
+template <int kBN>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const float* __restrict__ bias,
                                                          _Float16* __restrict__ y, ConvArgs a)
 {
@@ -72,7 +74,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const _Float16* __restr
         wi0[i] = (int)wo * a.stride - a.pad;
         px[i] = x + (size_t)b * a.H * a.W * a.C;
     }
-    const bool wv = n0 + r < a.N;
+    constexpr int kNT = kBN / 32;                            // 32-channel MFMA tiles per wave
+    const bool wv = r < kBN && n0 + r < a.N;
     const _Float16* wrow = w + (size_t)(wv ? n0 + r : 0) * n_stage * kBK;      // weight rows are padded to whole stages
 
     half8 ra[2], rb;
@@ -95,12 +98,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const _Float16* __restr
         const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
         *reinterpret_cast<half8*>(&As[buf][r * kRow + ck * 8]) = oka[0] ? ra[0] : z;
         *reinterpret_cast<half8*>(&As[buf][(r + 64) * kRow + ck * 8]) = oka[1] ? ra[1] : z;
-        *reinterpret_cast<half8*>(&Bs[buf][r * kRow + ck * 8]) = wv ? rb : z;
+        if (r < kBN) *reinterpret_cast<half8*>(&Bs[buf][r * kRow + ck * 8]) = wv ? rb : z;
     };
 
-    float16v acc[2];
+    float16v acc[kNT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < kNT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 
@@ -115,10 +118,11 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const _Float16* __restr
 #pragma unroll
         for (int k16 = 0; k16 < kBK / 16; ++k16) {
             const half8 af = *reinterpret_cast<const half8*>(A + 16 * k16);
-            const half8 b0 = *reinterpret_cast<const half8*>(Bp + 16 * k16);
-            const half8 b1 = *reinterpret_cast<const half8*>(Bp + 32 * kRow + 16 * k16);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b1, acc[1], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) {
+                const half8 bf = *reinterpret_cast<const half8*>(Bp + 32 * t * kRow + 16 * k16);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[t], 0, 0, 0);
+            }
         }
         if (s + 1 < n_stage) stash(buf ^ 1);                   // the other buffer: its readers passed the previous barrier
         __syncthreads();
@@ -130,7 +134,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const _Float16* __restr
     _Float16* Cs = &As[0][0];
     static_assert(kBM * kCRow <= 2 * kBM * kRow, "the output tile fits the pixel tile's two buffers");
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < kNT; ++t) {
         const int n = n0 + 32 * t + (lane & 31);
         const float bn = (bias && n < a.N) ? bias[n] : 0.0f;
 #pragma unroll
@@ -142,9 +146,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const _Float16* __restr
     }
     __syncthreads();
     const bool wide = a.wide != 0;                             // 16-byte stores need 16-byte rows and bases (launch_conv2d_nhwc_f16)
+    constexpr int kCC = kBN / 8;                             // 16-byte chunks per tile row
 #pragma unroll
-    for (int j = 0; j < (kBM * kBN / 8) / 256; ++j) {
-        const int id = tid + 256 * j, row = id >> 3, cc = (id & 7) * 8;
+    for (int j = 0; j < (kBM * kCC) / 256; ++j) {
+        const int id = tid + 256 * j, row = id / kCC, cc = (id % kCC) * 8;
         const long long m = m0 + row;
         if (m >= a.M || n0 + cc >= a.N) continue;
         const _Float16* src = &Cs[row * kCRow + cc];
@@ -187,9 +192,13 @@ hipError_t launch_conv2d_nhwc_f16(const void* x, const void* w, const float* bia
     a.M = (long long)B * a.Ho * a.Wo;
     if (a.M > 0x7fffffffLL) return hipErrorInvalidValue;       // (the kernel splits pixel indices in 32 bits)
     const long long gx = (a.M + kBM - 1) / kBM;
-    const dim3 grid((unsigned)gx, (unsigned)((N + kBN - 1) / kBN));
-    hipLaunchKernelGGL(conv_igemm_kernel, grid, dim3(256), 0, stream, static_cast<const _Float16*>(x), static_cast<const _Float16*>(w), bias,
-                       static_cast<_Float16*>(y), a);
+    if (N <= 32) {
+        hipLaunchKernelGGL(conv_igemm_kernel<32>, dim3((unsigned)gx, 1u), dim3(256), 0, stream, static_cast<const _Float16*>(x), static_cast<const _Float16*>(w),
+                           bias, static_cast<_Float16*>(y), a);
+    } else {
+        hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3((unsigned)gx, (unsigned)((N + 63) / 64)), dim3(256), 0, stream, static_cast<const _Float16*>(x),
+                           static_cast<const _Float16*>(w), bias, static_cast<_Float16*>(y), a);
+    }
     return hipGetLastError();
 }
 
