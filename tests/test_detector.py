@@ -167,6 +167,7 @@ CONV_CASES = [  # (B, Cin, H, W, Cout, k, stride, pad, silu)      the layer shap
     (1, 1024, 10, 10, 512, 1, 1, 0, True),    # SPPF's second 1x1: the deepest K
     (2, 256, 16, 16, 18, 1, 1, 0, False),     # a detect level: 18 outputs (a ragged channel tile), bias only
     (1, 512, 7, 9, 512, 3, 2, 1, True),       # odd sizes under stride 2
+    (1, 64, 12, 12, 160, 3, 1, 1, True),      # 128-channel tiles (2 x 2 wave grid), the second one a quarter full
 ]
 
 

@@ -35,7 +35,10 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
 constexpr int kBM = 128, kBK = 32, kRow = kBK + 8;   // halfs per LDS row (80 bytes)
-// kBN (template parameter): output channels per workgroup tile, 64 or -- for layers of up to 32 channels, the 6x6 stem among them -- 32
+// kBN (template parameter): output channels per workgroup tile.
+//   32: layers of up to 32 channels (the 6x6 stem among them); 64; 128 for layers of 128 channels and more -- there the four waves
+//   form a 2 x 2 grid of 64-pixel x 64-channel tiles (two A and two B fragments feed four MFMAs: one LDS read per MFMA instead of 1.5,
+//   a third less staging per MFMA), otherwise they stack 4 x 1 with 32-pixel x kBN tiles.
 
 struct ConvArgs {
     int B, H, W, C, Ho, Wo, N, KH, KW, stride, pad, act;
@@ -50,15 +53,20 @@ template <int kBN>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const float* __restrict__ bias,
                                                          _Float16* __restrict__ y, ConvArgs a)
 {
-    __shared__ __attribute__((aligned(16))) _Float16 As[2][kBM * kRow];
-    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][kBN * kRow];
+    constexpr int kWN = kBN == 128 ? 2 : 1, kWM = 4 / kWN;              // the waves' grid over the tile
+    constexpr int kTM = kBM / kWM / 32, kTN = kBN / kWN / 32;           // 32 x 32 MFMA tiles per wave
+    constexpr int kBRows = (kBN + 63) / 64;                             // weight rows a thread moves per stage
+    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * (kBM + kBN) * kRow];
+    _Float16* const As = smem;                                          // [2][kBM][kRow]
+    _Float16* const Bs = smem + 2 * kBM * kRow;                         // [2][kBN][kRow]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % kWM, wn = wave / kWM;
     const long long m0 = (long long)blockIdx.x * kBM;
     const int n0 = blockIdx.y * kBN;
     // K is walked in 16-byte chunks of 8 halfs: chunk q = (kh, 8 (q % cpk) halfs into the kh run of KW * C); 4 chunks per stage
     const int cpk = (a.KW * a.C) >> 3, n_chunk = a.KH * cpk, n_stage = (n_chunk + 3) >> 2;
 
-    // this thread's chunks: pixel rows r and r + 64, chunk `ck` of the stage; weight row r, same chunk
+    // this thread's chunks: pixel rows r and r + 64, chunk `ck` of the stage; weight rows r (+ 64), same chunk
     const int r = tid >> 2, ck = tid & 3;
     int hi0[2], wi0[2];
     const _Float16* px[2];
@@ -74,11 +82,15 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const _Float16* __restr
         wi0[i] = (int)wo * a.stride - a.pad;
         px[i] = x + (size_t)b * a.H * a.W * a.C;
     }
-    constexpr int kNT = kBN / 32;                            // 32-channel MFMA tiles per wave
-    const bool wv = r < kBN && n0 + r < a.N;
-    const _Float16* wrow = w + (size_t)(wv ? n0 + r : 0) * n_stage * kBK;      // weight rows are padded to whole stages
+    bool wv[kBRows];
+    const _Float16* wrow[kBRows];
+#pragma unroll
+    for (int i = 0; i < kBRows; ++i) {
+        wv[i] = r + 64 * i < kBN && n0 + r + 64 * i < a.N;
+        wrow[i] = w + (size_t)(wv[i] ? n0 + r + 64 * i : 0) * n_stage * kBK;      // weight rows are padded to whole stages
+    }
 
-    half8 ra[2], rb;
+    half8 ra[2], rb[kBRows];
     bool oka[2];          // (the zero padding is applied when the chunk goes to LDS: a select right behind the load would wait for it there)
     auto fetch = [&](int s) {
         const int q = 4 * s + ck;
@@ -92,20 +104,25 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const _Float16* __restr
             ra[i] = *reinterpret_cast<const half8*>(px[i] + off);
             oka[i] = ok;
         }
-        rb = *reinterpret_cast<const half8*>(wrow + (size_t)q * 8);
+#pragma unroll
+        for (int i = 0; i < kBRows; ++i) rb[i] = *reinterpret_cast<const half8*>(wrow[i] + (size_t)q * 8);
     };
     auto stash = [&](int buf) {
         const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        *reinterpret_cast<half8*>(&As[buf][r * kRow + ck * 8]) = oka[0] ? ra[0] : z;
-        *reinterpret_cast<half8*>(&As[buf][(r + 64) * kRow + ck * 8]) = oka[1] ? ra[1] : z;
-        if (r < kBN) *reinterpret_cast<half8*>(&Bs[buf][r * kRow + ck * 8]) = wv ? rb : z;
+        *reinterpret_cast<half8*>(&As[(buf * kBM + r) * kRow + ck * 8]) = oka[0] ? ra[0] : z;
+        *reinterpret_cast<half8*>(&As[(buf * kBM + r + 64) * kRow + ck * 8]) = oka[1] ? ra[1] : z;
+#pragma unroll
+        for (int i = 0; i < kBRows; ++i)
+            if (r + 64 * i < kBN) *reinterpret_cast<half8*>(&Bs[(buf * kBN + r + 64 * i) * kRow + ck * 8]) = wv[i] ? rb[i] : z;
     };
 
-    float16v acc[kNT];
+    float16v acc[kTM][kTN];
 #pragma unroll
-    for (int t = 0; t < kNT; ++t)
+    for (int i = 0; i < kTM; ++i)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+        for (int t = 0; t < kTN; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][t][e] = 0.0f;
 
     fetch(0);
     stash(0);
@@ -113,40 +130,46 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const _Float16* __restr
     for (int s = 0; s < n_stage; ++s) {
         const int buf = s & 1;
         if (s + 1 < n_stage) fetch(s + 1);                     // in flight under this stage's MFMAs
-        const _Float16* A = &As[buf][(wave * 32 + (lane & 31)) * kRow + 8 * (lane >> 5)];
-        const _Float16* Bp = &Bs[buf][(lane & 31) * kRow + 8 * (lane >> 5)];
+        const _Float16* A = &As[(buf * kBM + wm * 32 * kTM + (lane & 31)) * kRow + 8 * (lane >> 5)];
+        const _Float16* Bp = &Bs[(buf * kBN + wn * 32 * kTN + (lane & 31)) * kRow + 8 * (lane >> 5)];
 #pragma unroll
         for (int k16 = 0; k16 < kBK / 16; ++k16) {
-            const half8 af = *reinterpret_cast<const half8*>(A + 16 * k16);
+            half8 af[kTM], bf[kTN];
 #pragma unroll
-            for (int t = 0; t < kNT; ++t) {
-                const half8 bf = *reinterpret_cast<const half8*>(Bp + 32 * t * kRow + 16 * k16);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[t], 0, 0, 0);
-            }
+            for (int i = 0; i < kTM; ++i) af[i] = *reinterpret_cast<const half8*>(A + 32 * i * kRow + 16 * k16);
+#pragma unroll
+            for (int t = 0; t < kTN; ++t) bf[t] = *reinterpret_cast<const half8*>(Bp + 32 * t * kRow + 16 * k16);
+#pragma unroll
+            for (int i = 0; i < kTM; ++i)
+#pragma unroll
+                for (int t = 0; t < kTN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[t], acc[i][t], 0, 0, 0);
         }
         if (s + 1 < n_stage) stash(buf ^ 1);                   // the other buffer: its readers passed the previous barrier
         __syncthreads();
     }
 
     // Epilogue.  C lane map of v_mfma_f32_32x32x16_f16: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-    // The f16 tile goes through LDS (the pixel tile's buffers are free after the loop's last barrier): rows of 64 channels + 8.
+    // The f16 tile goes through LDS (the stage buffers are free after the loop's last barrier): rows of kBN channels + 8.
     constexpr int kCRow = kBN + 8;
-    _Float16* Cs = &As[0][0];
-    static_assert(kBM * kCRow <= 2 * kBM * kRow, "the output tile fits the pixel tile's two buffers");
+    _Float16* Cs = smem;
+    static_assert(kBM * kCRow <= 2 * (kBM + kBN) * kRow, "the output tile fits the stage buffers");
 #pragma unroll
-    for (int t = 0; t < kNT; ++t) {
-        const int n = n0 + 32 * t + (lane & 31);
+    for (int t = 0; t < kTN; ++t) {
+        const int col = wn * 32 * kTN + 32 * t + (lane & 31), n = n0 + col;
         const float bn = (bias && n < a.N) ? bias[n] : 0.0f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            float v = acc[t][i] + bn;
-            if (a.act) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));      // SiLU (1 ulp reciprocal, rounded to f16 next)
-            Cs[(wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * kCRow + 32 * t + (lane & 31)] = (_Float16)v;
+        for (int i = 0; i < kTM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[i][t][e] + bn;
+                if (a.act) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));      // SiLU (1 ulp reciprocal, rounded to f16 next)
+                Cs[(wm * 32 * kTM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * kCRow + col] = (_Float16)v;
+            }
         }
     }
     __syncthreads();
     const bool wide = a.wide != 0;                             // 16-byte stores need 16-byte rows and bases (launch_conv2d_nhwc_f16)
-    constexpr int kCC = kBN / 8;                             // 16-byte chunks per tile row
+    constexpr int kCC = kBN / 8;                               // 16-byte chunks per tile row
 #pragma unroll
     for (int j = 0; j < (kBM * kCC) / 256; ++j) {
         const int id = tid + 256 * j, row = id / kCC, cc = (id % kCC) * 8;
@@ -192,7 +215,10 @@ hipError_t launch_conv2d_nhwc_f16(const void* x, const void* w, const float* bia
     a.M = (long long)B * a.Ho * a.Wo;
     if (a.M > 0x7fffffffLL) return hipErrorInvalidValue;       // (the kernel splits pixel indices in 32 bits)
     const long long gx = (a.M + kBM - 1) / kBM;
-    if (N <= 32) {
+    if (N >= 128) {
+        hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3((unsigned)gx, (unsigned)((N + 127) / 128)), dim3(256), 0, stream, static_cast<const _Float16*>(x),
+                           static_cast<const _Float16*>(w), bias, static_cast<_Float16*>(y), a);
+    } else if (N <= 32) {
         hipLaunchKernelGGL(conv_igemm_kernel<32>, dim3((unsigned)gx, 1u), dim3(256), 0, stream, static_cast<const _Float16*>(x), static_cast<const _Float16*>(w),
                            bias, static_cast<_Float16*>(y), a);
     } else {
