@@ -234,6 +234,9 @@ int bf_yolo_decode_device(const void *const raw[3], const int h[3], const int w[
  *       bitonic sort in LDS.  This is the candidate list bf_nms_device walks. */
 int bf_topk_candidates_device(const float *d_scores, const float *d_boxes, const int *d_cls, int batch, int total, int k, float *d_top_scores,
                               float *d_top_boxes, int *d_top_cls, int *d_counts, void *stream);
+/*   bf_preprocess_bgr8_device: camera frames uint8 [batch][h][w][3] BGR (as OpenCV delivers them, main.pyx:632) -> the network's input,
+ *       float16 NHWC [batch][h][w][cpad], RGB / 255 in channels 0..2, zeros above (cpad = 4: what the stem convolution reads). */
+int bf_preprocess_bgr8_device(const void *d_frames, void *d_out, int batch, int h, int w, int cpad, void *stream);
 /*   bf_conv2d_nhwc_f16_device: the detector's convolutions (the network behind ultralytics.YOLO, yolo_smooth_tracking.py:9-23) as an
  *       implicit GEMM on the f16 matrix cores: y[b][ho][wo][n] = act(bias[n] + sum x[b][ho*stride-pad+i][wo*stride-pad+j][c] * w[n][i][j][c]),
  *       x float16 NHWC [batch][h][w][c]; w float16 [n][kh][kw][c], every output channel's kh*kw*c values followed by zeros up to a

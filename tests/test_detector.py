@@ -249,3 +249,15 @@ def test_gpu_hip_convolution_into_a_slice_with_residual(native):
     assert torch.equal(buf[:, :C], x + plain_a) and torch.equal(buf[:, C:2 * C], plain_b) and bool((buf[:, 2 * C:] == 7.0).all())
     with pytest.raises(Exception):
         convs[0](x, out=buf[:, :C].permute(0, 1, 3, 2))
+
+
+@pytest.mark.gpu
+def test_gpu_preprocess_kernel_matches_torch(native):
+    """bf_preprocess_bgr8_device against frames.flip(-1).half() / 255: RGB order, the same float16 values, a zero fourth channel."""
+    import torch
+    from image_detection.src.yolo_smooth_tracking import Detector
+    frames = torch.randint(0, 256, (3, 64, 96, 3), dtype=torch.uint8, device="cuda")
+    x = Detector(conv_backend="hip").preprocess(frames)
+    want = frames.flip(-1).permute(0, 3, 1, 2).half() / 255
+    assert tuple(x.shape) == (3, 4, 64, 96) and x.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(x[:, :3], want) and bool((x[:, 3] == 0).all())

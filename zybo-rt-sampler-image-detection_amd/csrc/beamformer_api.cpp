@@ -1158,6 +1158,14 @@ int bf_topk_candidates_device(const float* d_scores, const float* d_boxes, const
                                              reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
 }
 
+int bf_preprocess_bgr8_device(const void* d_frames, void* d_out, int batch, int h, int w, int cpad, void* stream)
+{
+    std::lock_guard<std::mutex> lock(S().mu);
+    if (!d_frames || !d_out || batch < 1 || h < 1 || w < 1 || cpad < 3) { set_error("bf_preprocess_bgr8_device: batch %d, %d x %d, %d channels", batch, h, w, cpad); return -1; }
+    if (!ensure_device()) return -1;
+    return HIP_OK(bf::launch_preprocess_bgr8(d_frames, d_out, (long long)batch * h * w, cpad, reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
+}
+
 int bf_conv2d_weight_row(int kh, int kw, int c) { return kh > 0 && kw > 0 && c > 0 ? (kh * kw * c + 31) / 32 * 32 : -1; }
 
 static int conv2d_checked(const char* who, const void* d_x, const void* d_w, const float* d_bias, void* d_y, int batch, int h, int w, int c, int n, int kh, int kw,

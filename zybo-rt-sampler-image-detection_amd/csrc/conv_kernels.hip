@@ -192,7 +192,35 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const _Float16* __restr
     }
 }
 
+// Camera frames -> network input (yolo_smooth_tracking.py:9-23 hands ultralytics BGR uint8 frames; its letterbox-free part is
+// BGR -> RGB, / 255): [B][H][W][3] uint8 BGR -> [B][H][W][cpad] float16 RGB in [0, 1], channels 3.. zero -- the NHWC buffer the stem
+// convolution reads.  (float)u / 255 rounded to f16: what torch computes for half(u) / 255.
+__global__ void __launch_bounds__(256) preprocess_kernel(const uint8_t* __restrict__ in, _Float16* __restrict__ out, long long pixels, int cpad)
+{
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += (long long)gridDim.x * blockDim.x) {
+        const uint8_t* s = in + p * 3;
+        _Float16* d = out + p * cpad;
+        const _Float16 r = (_Float16)((float)s[2] / 255.0f), g = (_Float16)((float)s[1] / 255.0f), b = (_Float16)((float)s[0] / 255.0f);
+        if (cpad == 4) {
+            typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<half4*>(d) = half4{r, g, b, (_Float16)0.0f};
+        } else {
+            d[0] = r; d[1] = g; d[2] = b;
+            for (int c = 3; c < cpad; ++c) d[c] = (_Float16)0.0f;
+        }
+    }
+}
+
 }  // namespace
+
+hipError_t launch_preprocess_bgr8(const void* frames, void* out, long long pixels, int cpad, hipStream_t stream)
+{
+    if (pixels <= 0 || cpad < 3) return hipErrorInvalidValue;
+    const long long blocks = (pixels + 255) / 256;
+    hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream, static_cast<const uint8_t*>(frames),
+                       static_cast<_Float16*>(out), pixels, cpad);
+    return hipGetLastError();
+}
 
 hipError_t launch_conv2d_nhwc_f16(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C, int N, int KH, int KW, int stride,
                                   int pad, int act, int ldy, const void* res, int ldr, hipStream_t stream)

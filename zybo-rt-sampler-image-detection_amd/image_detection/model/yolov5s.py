@@ -146,8 +146,8 @@ class HipConv(nn.Module):
         channels_last [B, n, Ho, Wo] tensor (or slice) added to the rounded result."""
         from lib import _native as nat
         b, c, h, w = (int(v) for v in x.shape)
-        if x.dtype != torch.float16 or c != self.c:
-            raise nat.BeamformerError("HipConv: expects float16 input with %d channels, got %s with %d" % (self.c, x.dtype, c))
+        if x.dtype != torch.float16 or c not in (self.c, self.cp):
+            raise nat.BeamformerError("HipConv: expects float16 input with %d channels (or padded to %d), got %s with %d" % (self.c, self.cp, x.dtype, c))
         if c != self.cp:
             xp = torch.empty((b, self.cp, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
             xp[:, :c] = x

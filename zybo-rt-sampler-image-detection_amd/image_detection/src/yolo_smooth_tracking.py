@@ -41,8 +41,16 @@ class Detector:
         self._ws = {}
 
     def preprocess(self, frames_u8):
-        """uint8 [B, H, W, 3] (BGR as OpenCV delivers it, main.pyx:632) -> network input [B, 3, H, W] RGB in [0, 1], channels_last."""
+        """uint8 [B, H, W, 3] (BGR as OpenCV delivers it, main.pyx:632) -> network input [B, 3, H, W] RGB in [0, 1], channels_last
+        ([B, 4, H, W] with a zero fourth channel on the HIP convolution path)."""
         t = self.torch
+        if self.conv_backend == "hip" and frames_u8.dtype == t.uint8 and frames_u8.is_contiguous():
+            # one kernel, straight into the 4-channel NHWC buffer the stem convolution reads (channel 3 zero)
+            b, h, w, _ = frames_u8.shape
+            x = t.empty((b, 4, h, w), dtype=t.float16, device=frames_u8.device, memory_format=t.channels_last)
+            if nat.lib.bf_preprocess_bgr8_device(frames_u8.data_ptr(), x.data_ptr(), b, h, w, 4, t.cuda.current_stream().cuda_stream) != 0:
+                nat.check()
+            return x
         x = frames_u8.flip(-1).permute(0, 3, 1, 2)
         x = (x.half() if self.half else x.float()) / 255
         return x.contiguous(memory_format=t.channels_last)
