@@ -68,6 +68,18 @@ def test_gpu_reference_named_caller(native):
     frame = np.random.default_rng(2).integers(0, 256, (640, 640, 3), dtype=np.uint8)
     dets = m.get_detections(frame, conf_threshold=0.1)
     assert isinstance(dets, list) and all(len(d) == 5 and d[4] >= 0.1 for d in dets)
+    # the reference's camera frame, 360 x 640 (main.pyx:632): letterboxed to 384 x 640 inside, boxes back in frame coordinates;
+    # the same picture handed over already padded gives the same boxes 12 rows lower
+    small = frame[:360]
+    got = m.get_detections(small, conf_threshold=0.001)
+    assert got and all(0 <= d[0] <= d[2] <= 640 and 0 <= d[1] <= d[3] <= 360 for d in got)
+    padded = np.full((384, 640, 3), 114, dtype=np.uint8)
+    padded[12:372] = small
+    ref = m.get_detections(padded, conf_threshold=0.001)
+    assert len(ref) == len(got)
+    for a, b in zip(got, ref):
+        assert a[4] == b[4] and a[0] == b[0] and a[2] == b[2]
+        assert a[1] == min(max(b[1] - 12, 0.0), 360.0) and a[3] == min(max(b[3] - 12, 0.0), 360.0)
     valid, cand = Y.split_detections([[0, 0, 1, 1, 0.7], [0, 0, 1, 1, 0.3], [0, 0, 1, 1, 0.05]])
     assert len(valid) == 1 and len(cand) == 1
     assert abs(Y.compute_iou([0, 0, 10, 10], [5, 5, 15, 15]) - 25 / 175) < 1e-12

@@ -107,12 +107,31 @@ class yolo_model:
         self.model = Detector(model_path)
 
     def get_detections(self, frame, conf_threshold=0.0):
-        """frame: uint8 [H, W, 3] BGR (H, W multiples of 32) -> [[x1, y1, x2, y2, conf], ...] with conf >= conf_threshold."""
+        """frame: uint8 [H, W, 3] BGR -> [[x1, y1, x2, y2, conf], ...] in the frame's pixel coordinates, conf >= conf_threshold.
+        A frame whose sides are not multiples of the network's largest stride (the reference's camera frames are 360 x 640,
+        main.pyx:632) is letterboxed the way ultralytics' predict does at scale 1: centred in the next multiple of 32 on a grey (114)
+        border, and the boxes are shifted back and clipped to the frame."""
         t = self.model.torch
-        f = t.from_numpy(np.ascontiguousarray(frame)).to(self.model.device).unsqueeze(0)
-        out, n = self.model.detect(f, conf_thres=max(1e-3, min(conf_threshold, 0.25)) if conf_threshold > 0 else 0.25)
+        frame = np.ascontiguousarray(frame)
+        H, W = int(frame.shape[0]), int(frame.shape[1])
+        Hp, Wp = -(-H // 32) * 32, -(-W // 32) * 32
+        top, left = (Hp - H) // 2, (Wp - W) // 2
+        f = t.from_numpy(frame).to(self.model.device)
+        if (Hp, Wp) != (H, W):
+            padded = t.full((Hp, Wp, 3), 114, dtype=t.uint8, device=self.model.device)
+            padded[top:top + H, left:left + W] = f
+            f = padded
+        out, n = self.model.detect(f.unsqueeze(0), conf_thres=max(1e-3, min(conf_threshold, 0.25)) if conf_threshold > 0 else 0.25)
         out, n = out[0].cpu().numpy(), int(n[0].item())
-        return [[*map(float, out[i, :4]), float(out[i, 4])] for i in range(n) if out[i, 4] >= conf_threshold]
+        dets = []
+        for i in range(n):
+            if out[i, 4] < conf_threshold:
+                continue
+            x1, y1, x2, y2 = (float(v) for v in out[i, :4])
+            x1, x2 = min(max(x1 - left, 0.0), float(W)), min(max(x2 - left, 0.0), float(W))
+            y1, y2 = min(max(y1 - top, 0.0), float(H)), min(max(y2 - top, 0.0), float(H))
+            dets.append([x1, y1, x2, y2, float(out[i, 4])])
+        return dets
 
 
 def compute_iou(box1, box2):
