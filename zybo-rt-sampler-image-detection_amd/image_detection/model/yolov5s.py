@@ -132,6 +132,8 @@ class HipConv(nn.Module):
         cp = 4
         while cp < c or (kw * cp) % 8:
             cp *= 2
+        if cp == 4 and (int(conv.stride[0]) % 2 or int(conv.padding[0]) % 2):
+            cp = 8                                          # 4 channels only under the stem's even geometry (bf_conv2d_nhwc_f16_device)
         wk = torch.zeros((n, kh, kw, cp), dtype=torch.float16, device=w.device)
         wk[..., :c] = w.permute(0, 2, 3, 1).to(torch.float16)
         wp = torch.zeros((n, nat.lib.bf_conv2d_weight_row(kh, kw, cp)), dtype=torch.float16, device=w.device)     # rows padded to whole K stages
