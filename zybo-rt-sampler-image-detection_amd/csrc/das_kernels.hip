@@ -2286,7 +2286,6 @@ __device__ __forceinline__ void hybrid_window_first(f32x4 (&Q)[6], HybridMasks& 
     BF_H_E(j, h01, w0) BF_H_O(j, h01, w1) BF_H_E(j, h23, w2) BF_H_O(j, h23, w3) BF_H_E(j, h45, w4) BF_H_O(j, h45, w5) BF_H_E(j, h67, w6) BF_H_O(j, h67, w7)
 __device__ __forceinline__ void hybrid_step(f32x2 (&o)[4], const f32x4 (&Q)[6], const unsigned long long (&h)[4], const HybridMasks& k)
 {
-    unsigned long long saved;
     // W[t] = (frame 0, frame 1) of the window's sample t: the two halves of the quads
     const f32x2 w0 = __builtin_shufflevector(Q[0], Q[0], 0, 1), w1 = __builtin_shufflevector(Q[0], Q[0], 2, 3);
     const f32x2 w2 = __builtin_shufflevector(Q[1], Q[1], 0, 1), w3 = __builtin_shufflevector(Q[1], Q[1], 2, 3);
@@ -2295,7 +2294,8 @@ __device__ __forceinline__ void hybrid_step(f32x2 (&o)[4], const f32x4 (&Q)[6], 
     const f32x2 w8 = __builtin_shufflevector(Q[4], Q[4], 0, 1), w9 = __builtin_shufflevector(Q[4], Q[4], 2, 3);
     const f32x2 w10 = __builtin_shufflevector(Q[5], Q[5], 0, 1);
     asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
+        // (EXEC is all ones on entry -- 1024-thread workgroups, the sweep sits behind wave-uniform branches only -- so it is
+        //  restored from the constant instead of being saved first: one scalar move and one SGPR pair less per step)
         "s_mov_b64 exec, %[m0]\n\t"
         BF_H_OUT(0, 0, 1, 2, 3, 4, 5, 6, 7)
         "s_mov_b64 exec, %[m1]\n\t"
@@ -2304,8 +2304,8 @@ __device__ __forceinline__ void hybrid_step(f32x2 (&o)[4], const f32x4 (&Q)[6], 
         BF_H_OUT(2, 2, 3, 4, 5, 6, 7, 8, 9)
         "s_mov_b64 exec, %[m3]\n\t"
         BF_H_OUT(3, 3, 4, 5, 6, 7, 8, 9, 10)
-        "s_mov_b64 exec, %[sv]"
-        : [o0] "+v"(o[0]), [o1] "+v"(o[1]), [o2] "+v"(o[2]), [o3] "+v"(o[3]), [sv] "=&s"(saved)
+        "s_mov_b64 exec, -1"
+        : [o0] "+v"(o[0]), [o1] "+v"(o[1]), [o2] "+v"(o[2]), [o3] "+v"(o[3])
         : [h01] "s"(h[0]), [h23] "s"(h[1]), [h45] "s"(h[2]), [h67] "s"(h[3]), [m0] "s"(k.m[0]), [m1] "s"(k.m[1]), [m2] "s"(k.m[2]), [m3] "s"(k.m[3]),
           [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3), [w4] "v"(w4), [w5] "v"(w5), [w6] "v"(w6), [w7] "v"(w7), [w8] "v"(w8), [w9] "v"(w9),
           [w10] "v"(w10));
