@@ -234,6 +234,10 @@ int bf_yolo_decode_device(const void *const raw[3], const int h[3], const int w[
  *       bitonic sort in LDS.  This is the candidate list bf_nms_device walks. */
 int bf_topk_candidates_device(const float *d_scores, const float *d_boxes, const int *d_cls, int batch, int total, int k, float *d_top_scores,
                               float *d_top_boxes, int *d_top_cls, int *d_counts, void *stream);
+/*   bf_sppf_pool_device: the SPPF block's pooling inside its concatenation buffer, float16 NHWC [batch][h][w][4*c]: channels [c, 2c),
+ *       [2c, 3c), [3c, 4c) become the 5x5 / stride 1 / pad 2 max pool of channels [0, c) applied once, twice and three times
+ *       (nn.MaxPool2d(5, 1, 2) cascaded; exact).  c a multiple of 8, h * w <= 2048. */
+int bf_sppf_pool_device(void *d_buf, int batch, int h, int w, int c, void *stream);
 /*   bf_preprocess_bgr8_device: camera frames uint8 [batch][h][w][3] BGR (as OpenCV delivers them, main.pyx:632) -> the network's input,
  *       float16 NHWC [batch][h][w][cpad], RGB / 255 in channels 0..2, zeros above (cpad = 4: what the stem convolution reads). */
 int bf_preprocess_bgr8_device(const void *d_frames, void *d_out, int batch, int h, int w, int cpad, void *stream);

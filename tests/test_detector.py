@@ -273,3 +273,19 @@ def test_gpu_preprocess_kernel_matches_torch(native):
     want = frames.flip(-1).permute(0, 3, 1, 2).half() / 255
     assert tuple(x.shape) == (3, 4, 64, 96) and x.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(x[:, :3], want) and bool((x[:, 3] == 0).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,H,W", [(2, 256, 20, 20), (1, 64, 12, 20), (3, 8, 5, 3)])
+def test_gpu_sppf_pool_kernel_matches_torch(native, B, C, H, W):
+    """bf_sppf_pool_device against nn.MaxPool2d(5, 1, 2) applied once, twice, three times: exact; the first quarter untouched."""
+    import torch
+    from lib import _native as nat
+    g = torch.Generator(device="cpu").manual_seed(C + H)
+    x = torch.randn((B, C, H, W), generator=g).cuda().half()
+    buf = torch.zeros((B, 4 * C, H, W), dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+    buf[:, :C] = x
+    assert nat.lib.bf_sppf_pool_device(buf.data_ptr(), B, H, W, C, torch.cuda.current_stream().cuda_stream) == 0, nat.check()
+    m = torch.nn.MaxPool2d(5, 1, 2)
+    y1 = m(x); y2 = m(y1); y3 = m(y2)
+    assert torch.equal(buf, torch.cat((x, y1, y2, y3), 1))

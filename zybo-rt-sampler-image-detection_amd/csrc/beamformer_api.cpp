@@ -1158,6 +1158,17 @@ int bf_topk_candidates_device(const float* d_scores, const float* d_boxes, const
                                              reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
 }
 
+int bf_sppf_pool_device(void* d_buf, int batch, int h, int w, int c, void* stream)
+{
+    std::lock_guard<std::mutex> lock(S().mu);
+    if (!d_buf || batch < 1 || h < 1 || w < 1 || c < 8 || (c & 7) != 0 || (long long)h * w > 2048) {
+        set_error("bf_sppf_pool_device: batch %d, %d x %d, %d channels (a multiple of 8; at most 2048 pixels per plane)", batch, h, w, c);
+        return -1;
+    }
+    if (!ensure_device()) return -1;
+    return HIP_OK(bf::launch_sppf_pool(d_buf, batch, h, w, c, reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
+}
+
 int bf_preprocess_bgr8_device(const void* d_frames, void* d_out, int batch, int h, int w, int cpad, void* stream)
 {
     std::lock_guard<std::mutex> lock(S().mu);

@@ -211,7 +211,62 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const uint8_t* __restri
     }
 }
 
+// SPPF (the network's spatial-pyramid block): y1 = maxpool5(x), y2 = maxpool5(y1), y3 = maxpool5(y2), stride 1, "same" padding, written
+// next to x in the concatenation buffer [B][H][W][4c] (x = channels [0, c), written by the block's first convolution).  One workgroup
+// per (image, 8-channel chunk): the H x W x 8 plane sits in LDS (16 bytes per pixel), each pool is a row pass and a column pass.
+typedef _Float16 half8p __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ half8p max8(half8p a, half8p b)
+{
+    half8p r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = a[e] > b[e] ? a[e] : b[e];
+    return r;
+}
+__global__ void __launch_bounds__(256) sppf_pool_kernel(_Float16* __restrict__ buf, int H, int W, int c)
+{
+    extern __shared__ __attribute__((aligned(16))) _Float16 plane[];          // [2][H * W] half8: current plane, row-pass result
+    half8p* cur = reinterpret_cast<half8p*>(plane);
+    half8p* tmp = cur + H * W;
+    const int chunks = c >> 3, b = blockIdx.x / chunks, ch = (blockIdx.x % chunks) * 8, ld = 4 * c, P = H * W;
+    _Float16* img = buf + (size_t)b * P * ld + ch;
+    for (int p = threadIdx.x; p < P; p += 256) cur[p] = *reinterpret_cast<const half8p*>(img + (size_t)p * ld);
+    __syncthreads();
+    for (int level = 1; level <= 3; ++level) {
+        for (int p = threadIdx.x; p < P; p += 256) {          // max over the row window
+            const int h = p / W, w = p - h * W;
+            half8p m = cur[p];
+            for (int d = 1; d <= 2; ++d) {
+                if (w - d >= 0) m = max8(m, cur[p - d]);
+                if (w + d < W) m = max8(m, cur[p + d]);
+            }
+            tmp[p] = m;
+        }
+        __syncthreads();
+        for (int p = threadIdx.x; p < P; p += 256) {          // max over the column window, into the plane and the level's channel slice
+            const int h = p / W;
+            half8p m = tmp[p];
+            for (int d = 1; d <= 2; ++d) {
+                if (h - d >= 0) m = max8(m, tmp[p - d * W]);
+                if (h + d < H) m = max8(m, tmp[p + d * W]);
+            }
+            cur[p] = m;       // (each thread rewrites only its own pixels of `cur`, which this pass does not read)
+            *reinterpret_cast<half8p*>(img + (size_t)p * ld + level * c) = m;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
+
+hipError_t launch_sppf_pool(void* buf, int B, int H, int W, int c, hipStream_t stream)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || c < 8 || (c & 7) != 0 || (long long)H * W > 2048) return hipErrorInvalidValue;
+    const size_t lds = (size_t)2 * H * W * 16;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sppf_pool_kernel, dim3((unsigned)(B * (c >> 3))), dim3(256), lds, stream, static_cast<_Float16*>(buf), H, W, c);
+    return hipGetLastError();
+}
 
 hipError_t launch_preprocess_bgr8(const void* frames, void* out, long long pixels, int cpad, hipStream_t stream)
 {

@@ -77,6 +77,16 @@ class SPPF(nn.Module):
         self.m = nn.MaxPool2d(k, 1, k // 2)
 
     def forward(self, x):
+        if isinstance(self.cv1.conv, HipConv) and x.shape[2] * x.shape[3] <= 2048:
+            # cv1 writes the first quarter of the concatenation buffer, one kernel fills the other three with the cascaded pools
+            from lib import _native as nat
+            b, _, h, w = (int(v) for v in x.shape)
+            c_ = self.cv1.conv.n
+            buf = torch.empty((b, 4 * c_, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            self.cv1(x, out=buf[:, :c_])
+            if nat.lib.bf_sppf_pool_device(buf.data_ptr(), b, h, w, c_, torch.cuda.current_stream().cuda_stream) != 0:
+                nat.check()
+            return self.cv2(buf)
         x = self.cv1(x)
         y1 = self.m(x)
         y2 = self.m(y1)
