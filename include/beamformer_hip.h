@@ -234,6 +234,9 @@ int bf_yolo_decode_device(const void *const raw[3], const int h[3], const int w[
  *       bitonic sort in LDS.  This is the candidate list bf_nms_device walks. */
 int bf_topk_candidates_device(const float *d_scores, const float *d_boxes, const int *d_cls, int batch, int total, int k, float *d_top_scores,
                               float *d_top_boxes, int *d_top_cls, int *d_counts, void *stream);
+/*   bf_upsample_concat_device: the head's torch.cat((nn.Upsample(2, "nearest")(a), b), 1) in one pass -- a float16 NHWC [batch][h/2][w/2][ca],
+ *       b [batch][h][w][cb], out [batch][h][w][ca + cb]; h, w even, ca, cb multiples of 8. */
+int bf_upsample_concat_device(const void *d_a, const void *d_b, void *d_out, int batch, int h, int w, int ca, int cb, void *stream);
 /*   bf_sppf_pool_device: the SPPF block's pooling inside its concatenation buffer, float16 NHWC [batch][h][w][4*c]: channels [c, 2c),
  *       [2c, 3c), [3c, 4c) become the 5x5 / stride 1 / pad 2 max pool of channels [0, c) applied once, twice and three times
  *       (nn.MaxPool2d(5, 1, 2) cascaded; exact).  c a multiple of 8, h * w <= 2048. */

@@ -289,3 +289,16 @@ def test_gpu_sppf_pool_kernel_matches_torch(native, B, C, H, W):
     m = torch.nn.MaxPool2d(5, 1, 2)
     y1 = m(x); y2 = m(y1); y3 = m(y2)
     assert torch.equal(buf, torch.cat((x, y1, y2, y3), 1))
+
+
+@pytest.mark.gpu
+def test_gpu_upsample_concat_kernel_matches_torch(native):
+    import torch
+    from lib import _native as nat
+    g = torch.Generator(device="cpu").manual_seed(3)
+    cl = torch.channels_last
+    a = torch.randn((2, 24, 6, 10), generator=g).cuda().half().contiguous(memory_format=cl)
+    b = torch.randn((2, 16, 12, 20), generator=g).cuda().half().contiguous(memory_format=cl)
+    out = torch.empty((2, 40, 12, 20), dtype=torch.float16, device="cuda").contiguous(memory_format=cl)
+    assert nat.lib.bf_upsample_concat_device(a.data_ptr(), b.data_ptr(), out.data_ptr(), 2, 12, 20, 24, 16, torch.cuda.current_stream().cuda_stream) == 0, nat.check()
+    assert torch.equal(out, torch.cat((torch.nn.Upsample(scale_factor=2, mode="nearest")(a), b), 1))

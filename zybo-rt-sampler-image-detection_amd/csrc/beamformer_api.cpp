@@ -1158,6 +1158,17 @@ int bf_topk_candidates_device(const float* d_scores, const float* d_boxes, const
                                              reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
 }
 
+int bf_upsample_concat_device(const void* d_a, const void* d_b, void* d_out, int batch, int h, int w, int ca, int cb, void* stream)
+{
+    std::lock_guard<std::mutex> lock(S().mu);
+    if (!d_a || !d_b || !d_out || batch < 1 || h < 2 || w < 2 || (h & 1) || (w & 1) || ca < 8 || cb < 8 || (ca & 7) || (cb & 7)) {
+        set_error("bf_upsample_concat_device: batch %d, %d x %d (even), %d + %d channels (multiples of 8)", batch, h, w, ca, cb);
+        return -1;
+    }
+    if (!ensure_device()) return -1;
+    return HIP_OK(bf::launch_upsample_concat(d_a, d_b, d_out, batch, h, w, ca, cb, reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
+}
+
 int bf_sppf_pool_device(void* d_buf, int batch, int h, int w, int c, void* stream)
 {
     std::lock_guard<std::mutex> lock(S().mu);

@@ -256,7 +256,36 @@ __global__ void __launch_bounds__(256) sppf_pool_kernel(_Float16* __restrict__ b
     }
 }
 
+// The head's torch.cat((upsample2x(a), b), 1) as one pass: out[b][y][x] = (a[b][y / 2][x / 2][0..ca), b[b][y][x][0..cb)), NHWC f16, 16-byte chunks.
+__global__ void __launch_bounds__(256) upsample_concat_kernel(const _Float16* __restrict__ a, const _Float16* __restrict__ b, _Float16* __restrict__ out,
+                                                              int H, int W, int ca, int cb, long long chunks)
+{
+    const int cpa = ca >> 3, cpp = (ca + cb) >> 3;             // chunks of a pixel from a, chunks per output pixel
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (long long)gridDim.x * blockDim.x) {
+        const long long pix = i / cpp;
+        const int k = (int)(i - pix * cpp);
+        half8p v;
+        if (k < cpa) {
+            const int x = (int)(pix % W), y = (int)((pix / W) % H);
+            const long long img = pix / ((long long)W * H);
+            v = *reinterpret_cast<const half8p*>(a + ((img * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * ca + 8 * k);
+        } else {
+            v = *reinterpret_cast<const half8p*>(b + pix * cb + 8 * (k - cpa));
+        }
+        *reinterpret_cast<half8p*>(out + i * 8) = v;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_upsample_concat(const void* a, const void* b, void* out, int B, int H, int W, int ca, int cb, hipStream_t stream)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || ca < 8 || cb < 8 || (ca & 7) || (cb & 7)) return hipErrorInvalidValue;
+    const long long chunks = (long long)B * H * W * ((ca + cb) >> 3), blocks = (chunks + 255) / 256;
+    hipLaunchKernelGGL(upsample_concat_kernel, dim3((unsigned)(blocks < 262144 ? blocks : 262144)), dim3(256), 0, stream, static_cast<const _Float16*>(a),
+                       static_cast<const _Float16*>(b), static_cast<_Float16*>(out), H, W, ca, cb, chunks);
+    return hipGetLastError();
+}
 
 hipError_t launch_sppf_pool(void* buf, int B, int H, int W, int c, hipStream_t stream)
 {

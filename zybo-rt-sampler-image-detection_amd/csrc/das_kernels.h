@@ -131,6 +131,8 @@ hipError_t read_phase_stamps(unsigned long long* out16, bool clear);
 // detector post-processing (nms_kernels.hip): YOLOv5 head decode + confidence filter, greedy NMS over score-sorted candidates
 hipError_t launch_yolo_decode(const void* const raw[3], const int hs[3], const int ws[3], const int strides[3], const float* anchors,
                               int batch, int nc, int is_half, float conf_thres, float* d_boxes, float* d_scores, int* d_cls, hipStream_t stream);
+// out [B][H][W][ca + cb] = (nearest 2x upsampling of a [B][H/2][W/2][ca], b [B][H][W][cb]), NHWC f16 (conv_kernels.hip)
+hipError_t launch_upsample_concat(const void* a, const void* b, void* out, int B, int H, int W, int ca, int cb, hipStream_t stream);
 // SPPF pooling inside the concatenation buffer [B][H][W][4c] f16: channels [c, 4c) = the three cascaded 5x5 max pools of channels [0, c) (conv_kernels.hip)
 hipError_t launch_sppf_pool(void* buf, int B, int H, int W, int c, hipStream_t stream);
 // uint8 BGR frames [pixels][3] -> float16 RGB / 255 [pixels][cpad], channels 3.. zero (conv_kernels.hip)

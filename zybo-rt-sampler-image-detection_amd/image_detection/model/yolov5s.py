@@ -110,13 +110,25 @@ class YOLOv5s(nn.Module):
         self.up = nn.Upsample(scale_factor=2, mode="nearest")
         self.detect = nn.ModuleList(nn.Conv2d(c, 3 * self.no, 1) for c in (128, 256, 512))
 
+    def up_cat(self, a, b):
+        """torch.cat((self.up(a), b), 1); on the HIP convolution path one kernel (bf_upsample_concat_device)."""
+        cl = torch.channels_last
+        if isinstance(self.h10.conv, HipConv) and a.dtype == torch.float16 and a.is_contiguous(memory_format=cl) and b.is_contiguous(memory_format=cl):
+            from lib import _native as nat
+            n, ca, cb, h, w = int(a.shape[0]), int(a.shape[1]), int(b.shape[1]), int(b.shape[2]), int(b.shape[3])
+            out = torch.empty((n, ca + cb, h, w), dtype=a.dtype, device=a.device, memory_format=cl)
+            if nat.lib.bf_upsample_concat_device(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, h, w, ca, cb, torch.cuda.current_stream().cuda_stream) != 0:
+                nat.check()
+            return out
+        return torch.cat((self.up(a), b), 1)
+
     def forward(self, x):
         p3 = self.b4(self.b3(self.b2(self.b1(self.b0(x)))))
         p4 = self.b6(self.b5(p3))
         p5 = self.b9(self.b8(self.b7(p4)))
         t10 = self.h10(p5)
-        t14 = self.h14(self.h13(torch.cat((self.up(t10), p4), 1)))
-        o3 = self.h17(torch.cat((self.up(t14), p3), 1))
+        t14 = self.h14(self.h13(self.up_cat(t10, p4)))
+        o3 = self.h17(self.up_cat(t14, p3))
         o4 = self.h20(torch.cat((self.h18(o3), t14), 1))
         o5 = self.h23(torch.cat((self.h21(o4), t10), 1))
         return [d(o) for d, o in zip(self.detect, (o3, o4, o5))]

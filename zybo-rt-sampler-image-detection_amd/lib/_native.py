@@ -104,6 +104,7 @@ _sig("bf_fd_covariance_device", C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_in
 _sig("bf_fd_cholesky_inverse_device", C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 _sig("bf_fd_mvdr_power_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
 _sig("bf_yolo_decode_device", C.c_int, C.POINTER(C.c_void_p), IP, IP, IP, FP, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_sig("bf_upsample_concat_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p)
 _sig("bf_sppf_pool_device", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p)
 _sig("bf_preprocess_bgr8_device", C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p)
 _sig("bf_conv2d_weight_row", C.c_int, C.c_int, C.c_int, C.c_int)
