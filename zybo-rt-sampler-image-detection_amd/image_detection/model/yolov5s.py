@@ -122,6 +122,16 @@ class YOLOv5s(nn.Module):
             return out
         return torch.cat((self.up(a), b), 1)
 
+    def conv_cat(self, conv, x, other):
+        """torch.cat((conv(x), other), 1); on the HIP convolution path the convolution writes its half of the buffer itself."""
+        if isinstance(conv.conv, HipConv):
+            n, c1, c2, h, w = int(other.shape[0]), conv.conv.n, int(other.shape[1]), int(other.shape[2]), int(other.shape[3])
+            buf = torch.empty((n, c1 + c2, h, w), dtype=other.dtype, device=other.device, memory_format=torch.channels_last)
+            conv(x, out=buf[:, :c1])
+            buf[:, c1:] = other
+            return buf
+        return torch.cat((conv(x), other), 1)
+
     def forward(self, x):
         p3 = self.b4(self.b3(self.b2(self.b1(self.b0(x)))))
         p4 = self.b6(self.b5(p3))
@@ -129,8 +139,8 @@ class YOLOv5s(nn.Module):
         t10 = self.h10(p5)
         t14 = self.h14(self.h13(self.up_cat(t10, p4)))
         o3 = self.h17(self.up_cat(t14, p3))
-        o4 = self.h20(torch.cat((self.h18(o3), t14), 1))
-        o5 = self.h23(torch.cat((self.h21(o4), t10), 1))
+        o4 = self.h20(self.conv_cat(self.h18, o3, t14))
+        o5 = self.h23(self.conv_cat(self.h21, o4, t10))
         return [d(o) for d, o in zip(self.detect, (o3, o4, o5))]
 
     def fuse(self):
