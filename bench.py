@@ -167,18 +167,24 @@ def extras(torch, nat, delays, mics, dev):
     nat.check()
     out["host_pointer_mimo_lerp"] = {"calls_per_s": 1.0 / dt, "us_per_call": dt * 1e6, "note": "one frame per call, host pointers, PCIe both ways, timed inside this process (torch loaded, other streams alive); "
                                                                                                     "scripts/host_path_latency.py measures the same call at 58 us standalone; real time needs 190.7 windows/s"}
-    # config 4
-    pipe = FusedPipeline("lerp", 640, dev)
-    pipe.load_tables(delays, mics)
+    # config 4: float32 first -- the precision the reference's detector call runs at (ultralytics' predict default,
+    # image-detection/src/yolo_smooth_tracking.py:13-23) -- then the float16 fast mode, labelled as such
     Bf = 64
     win = torch.from_numpy(synth.frame_batch(M, N, Bf)).to(dev)
     cam = torch.randint(0, 256, (Bf, 640, 640, 3), dtype=torch.uint8, device=dev)
-    dt = timed(lambda: pipe.step(win, cam), torch, 10)
-    out["fused_heatmap_overlay_yolo"] = {"frames_per_s": Bf / dt, "batch": Bf, "image": "640x640x3 uint8", "detector": "YOLOv5s-shaped, fp16 (ultralytics' default predict is fp32), random init, 1 class",
-                                         "conv_backend": pipe.detector.conv_backend}
-    x = pipe.detector.preprocess(cam)
-    dt = timed(lambda: pipe.detector.postprocess(pipe.detector.raw(x)), torch, 10)
-    out["yolo_only"] = {"detections_per_s": Bf / dt, "batch": Bf, "gflop_per_frame": 15.8, "dtype": "fp16", "conv_backend": pipe.detector.conv_backend}
+    for half, suffix in ((False, ""), (True, "_fp16_fast_mode")):
+        pipe = FusedPipeline("lerp", 640, dev, half=half)
+        pipe.load_tables(delays, mics)
+        dt = timed(lambda: pipe.step(win, cam), torch, 10)
+        prec = "fp16 (f32 accumulation; narrower than the reference's fp32 predict)" if half else "fp32 (= ultralytics' default predict precision; exact-f32 MFMA)"
+        out["fused_heatmap_overlay_yolo" + suffix] = {"frames_per_s": Bf / dt, "batch": Bf, "image": "640x640x3 uint8", "dtype": "fp16" if half else "fp32",
+                                                      "detector": "YOLOv5s-shaped, %s, random init, 1 class" % prec, "conv_backend": pipe.detector.conv_backend}
+        x = pipe.detector.preprocess(cam)
+        dt = timed(lambda: pipe.detector.postprocess(pipe.detector.raw(x)), torch, 10)
+        out["yolo_only" + suffix] = {"detections_per_s": Bf / dt, "batch": Bf, "gflop_per_frame": 15.8, "dtype": "fp16" if half else "fp32",
+                                     "conv_backend": pipe.detector.conv_backend, "mfma_tflops": 15.8e9 * Bf / dt / 1e12,
+                                     "mfma_peak_tflops": 2500.0 if half else 157.3}
+        del pipe, x
     # config 3 + frequency-domain DAS: same 64-mic array and 101x101 grid through the frequency-domain geometry
     old = (C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y)
     C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y = 64, 1, 101, 101
@@ -351,7 +357,8 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kernel_all = np.asarray([a.elapsed_time(b) for a, b in ev], dtype=np.float64)
+    kernel_ms = float(np.mean(kernel_all))
 
     assert torch.isfinite(d_part[0][:, : hi - lo]).all(), "non-finite beam power"
     if world > 1:
@@ -399,7 +406,8 @@ def main():
                          "frac": valu_achieved / VALU_PEAK_TLANEOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": {5: "copies::das_pair_kernel<%s>", 2: "copies::das_copies_kernel<%s>", 3: "copies::das_copies_kernel<%s, DIRECT>",
                                     4: "copies::das_copies_kernel<%s>", 6: "copies::das_long_kernel<%s>", 7: "copies::das_hybrid_pair_kernel<%s>", 8: "copies::das_pair2_kernel<%s>"}.get(nat.lib.bf_last_das_variant(), "das_mimo_kernel<%s>") % args.algo,
-                         "kernel_ms": kernel_ms, "gmacs_per_s": macs / (kernel_ms * 1e-3) / 1e9,
+                         "kernel_ms": kernel_ms, "kernel_ms_min": float(kernel_all.min()), "kernel_ms_median": float(np.median(kernel_all)),
+                         "kernel_ms_max": float(kernel_all.max()), "gmacs_per_s": macs / (kernel_ms * 1e-3) / 1e9,
                          "note": "gather-accumulate kernel, no MFMA: tables stay L2-resident across the frames of a launch and sample quads are "
                                  "re-read from LDS only when a direction's delay differs from its neighbour's, so HBM is nearly idle and the "
                                  "fp32 VALU binds (DESIGN.md section 5)",

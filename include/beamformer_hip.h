@@ -220,14 +220,15 @@ int bf_fd_mvdr_power_device(const float *d_lire_t, const float *d_liim_t, const 
 /* ---- detector post-processing (device pointers, enqueue only).  The reference obtains boxes from
  * ultralytics.YOLO(...).predict (image-detection/src/yolo_smooth_tracking.py:9-23); these are the published YOLOv5 head
  * decode and non-maximum suppression it performs internally.
- *   bf_yolo_decode_device: raw[l] = head output of level l, [batch][3*(5+nc)][h[l]][w[l]] (float32, or float16 when is_half);
+ *   bf_yolo_decode_device: raw[l] = head output of level l, [batch][3*(5+nc)][h[l]][w[l]] (format bit 0: float16 maps, else float32;
+ *       bit 1: the maps are NHWC, [batch][h][w][3*(5+nc)] -- the channels_last memory the detect convolutions write);
  *       anchors float32 [3][3][2] (pixels, HOST pointer); writes xyxy boxes [batch][T][4], scores [batch][T] (obj*cls, or -1
  *       when under conf_thres) and class ids [batch][T], T = 3 * sum(h*w).
  *   bf_nms_device: boxes / scores / cls of the K best candidates per image, already sorted by descending score, counts[b] valid
  *       entries; d_mask workspace uint64 [batch][K][ceil(K/64)]; writes up to max_det rows [x1,y1,x2,y2,score,cls] per image
  *       and the number kept.  K <= 4096. */
 int bf_yolo_decode_device(const void *const raw[3], const int h[3], const int w[3], const int strides[3], const float *anchors, int batch, int nc,
-                          int is_half, float conf_thres, float *d_boxes, float *d_scores, int *d_cls, void *stream);
+                          int format, float conf_thres, float *d_boxes, float *d_scores, int *d_cls, void *stream);
 /*   bf_topk_candidates_device: the k (<= 1024) best-scoring boxes of every image in descending score order (ties: lower box index
  *       first) -- d_top_scores [batch][k], d_top_boxes [batch][k][4], d_top_cls [batch][k], d_counts [batch] = entries with a
  *       positive score (decode marks rejected boxes with -1).  One workgroup per image: radix select, ordered tie admission,
@@ -260,6 +261,28 @@ int bf_conv2d_nhwc_f16_device(const void *d_x, const void *d_w, const float *d_b
  *       way two float16 tensors are added (the bottlenecks' x + cv2(cv1(x))). */
 int bf_conv2d_nhwc_f16_into_device(const void *d_x, const void *d_w, const float *d_bias, void *d_y, int ldy, const void *d_res, int ldr, int batch, int h,
                                    int w, int c, int n, int kh, int kw, int stride, int pad, int silu, void *stream);
+/*   float32 forms of the detector's tensor kernels -- the precision ultralytics' predict runs at by default
+ *       (yolo_smooth_tracking.py:13-23 passes no half=): the same kernels on float32 NHWC tensors, the convolution on the exact-f32 matrix
+ *       instruction v_mfma_f32_32x32x2_f32 (products and sums in f32, one rounding per product), SiLU as x / (1 + expf(-x)).
+ *       Weight rows are padded to a multiple of 16 floats (bf_conv2d_weight_row_f32); c a power of two >= 4. */
+int bf_conv2d_weight_row_f32(int kh, int kw, int c);
+int bf_conv2d_nhwc_f32_device(const void *d_x, const void *d_w, const float *d_bias, void *d_y, int batch, int h, int w, int c, int n, int kh, int kw,
+                              int stride, int pad, int silu, void *stream);
+int bf_conv2d_nhwc_f32_into_device(const void *d_x, const void *d_w, const float *d_bias, void *d_y, int ldy, const void *d_res, int ldr, int batch, int h,
+                                   int w, int c, int n, int kh, int kw, int stride, int pad, int silu, void *stream);
+int bf_upsample_concat_f32_device(const void *d_a, const void *d_b, void *d_out, int batch, int h, int w, int ca, int cb, void *stream);
+int bf_sppf_pool_f32_device(void *d_buf, int batch, int h, int w, int c, void *stream);
+int bf_preprocess_bgr8_f32_device(const void *d_frames, void *d_out, int batch, int h, int w, int cpad, void *stream);
+/*   bf_conv1x1_cat_nhwc_{f16,f32}_device: a 1x1 convolution (+ bias, SiLU, slice output, residual as above) whose input is a VIRTUAL
+ *       concatenation, so that the network's torch.cat((a, b), 1) and torch.cat((upsample(a), b), 1) in front of a 1x1 layer cost no
+ *       pass of their own: channels [0, c1) of pixel (b, y, x) are read from d_x1 (ld1 elements between consecutive pixels: a dense
+ *       tensor or a channel slice of a wider NHWC buffer; up1 != 0: d_x1 is [batch][h/2][w/2] and pixel (y/2, x/2) is read =
+ *       nn.Upsample(2, "nearest")), channels [c1, c) from d_x2 (pitch ld2; may be NULL when c1 == c).  c1, ld1, ld2 whole 16-byte
+ *       chunks, pointers 16-byte aligned.  d_w: [n][c] rows as bf_conv2d_weight_row(_f32)(1, 1, c). */
+int bf_conv1x1_cat_nhwc_f16_device(const void *d_x1, int ld1, int c1, int up1, const void *d_x2, int ld2, const void *d_w, const float *d_bias, void *d_y,
+                                   int ldy, const void *d_res, int ldr, int batch, int h, int w, int c, int n, int silu, void *stream);
+int bf_conv1x1_cat_nhwc_f32_device(const void *d_x1, int ld1, int c1, int up1, const void *d_x2, int ld2, const void *d_w, const float *d_bias, void *d_y,
+                                   int ldy, const void *d_res, int ldr, int batch, int h, int w, int c, int n, int silu, void *stream);
 int bf_nms_device(const float *d_boxes, const float *d_scores, const int *d_cls, const int *d_counts, int batch, int k, float iou_thres, int max_det,
                   unsigned long long *d_mask, float *d_out, int *d_out_count, void *stream);
 

@@ -19,7 +19,7 @@ def build():
     import __graft_entry__ as ge
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     srcs = [os.path.join(ge.CSRC, s) for s in ge.SOURCES]
-    cmd = ["/opt/rocm/bin/hipcc"] + ge.HIPCC_FLAGS + ["-DBF_STAMPS"] + srcs + ["-o", OUT]
+    cmd = ["/opt/rocm/bin/hipcc"] + ge.HIPCC_FLAGS + ["-shared", "-DBF_STAMPS"] + srcs + ["-o", OUT]
     subprocess.check_call(cmd)
     print("built", OUT)
 

@@ -18,12 +18,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "zybo-rt-sampler-image-detection_amd"))
 
 
-def build_pipeline():
+def build_pipeline(half=False):
     from interface import config
     from lib import directions
     from pipeline import FusedPipeline
     config.configure(N_MICROPHONES=64, ACTIVE_TILES=1, N_SAMPLES=256, MAX_RES_X=101, MAX_RES_Y=101, N_TAPS=8)
-    pipe = FusedPipeline("lerp", 640)
+    pipe = FusedPipeline("lerp", 640, half=half)
     pipe.load_tables(directions.calculate_delays(), np.arange(64))
     return pipe
 
@@ -74,8 +74,9 @@ def graph_vs_eager(pipe, B, seed=0, time_it=False):
 
 
 if __name__ == "__main__":
-    pipe = build_pipeline()
-    for B in [int(a) for a in sys.argv[1:]] or [1, 8, 64]:
+    half = "--half" in sys.argv
+    pipe = build_pipeline(half)
+    for B in [int(a) for a in sys.argv[1:] if a != "--half"] or [1, 8, 64]:
         r = graph_vs_eager(pipe, B, time_it=True)
         print("B=%d eager %.3f ms  graph %.3f ms  (%.2fx)  equal: %s" % (B, r["eager_ms"], r["graph_ms"], r["eager_ms"] / r["graph_ms"],
                                                                        {k: v for k, v in r.items() if isinstance(v, bool)}), flush=True)

@@ -1141,10 +1141,10 @@ void bf_jet_lut(unsigned char* out768)
 // ---------------------------------------------------------------- detector post-processing
 
 int bf_yolo_decode_device(const void* const raw[3], const int h[3], const int w[3], const int strides[3], const float* anchors, int batch, int nc,
-                          int is_half, float conf_thres, float* d_boxes, float* d_scores, int* d_cls, void* stream)
+                          int format, float conf_thres, float* d_boxes, float* d_scores, int* d_cls, void* stream)
 {
     FD_ENTER(raw && raw[0] && raw[1] && raw[2] && h && w && strides && anchors && d_boxes && d_scores && d_cls && batch > 0 && nc > 0, "bf_yolo_decode_device")
-    return HIP_OK(bf::launch_yolo_decode(raw, h, w, strides, anchors, batch, nc, is_half, conf_thres, d_boxes, d_scores, d_cls, st)) ? 0 : -1;
+    return HIP_OK(bf::launch_yolo_decode(raw, h, w, strides, anchors, batch, nc, format, conf_thres, d_boxes, d_scores, d_cls, st)) ? 0 : -1;
 }
 
 int bf_topk_candidates_device(const float* d_scores, const float* d_boxes, const int* d_cls, int batch, int total, int k, float* d_top_scores,
@@ -1158,68 +1158,128 @@ int bf_topk_candidates_device(const float* d_scores, const float* d_boxes, const
                                              reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
 }
 
+static int upsample_concat_checked(const char* who, int eb, const void* d_a, const void* d_b, void* d_out, int batch, int h, int w, int ca, int cb, void* stream)
+{
+    std::lock_guard<std::mutex> lock(S().mu);
+    const int E = 16 / eb;
+    if (!d_a || !d_b || !d_out || batch < 1 || h < 2 || w < 2 || (h & 1) || (w & 1) || ca < E || cb < E || (ca % E) || (cb % E)) {
+        set_error("%s: batch %d, %d x %d (even), %d + %d channels (multiples of %d)", who, batch, h, w, ca, cb, E);
+        return -1;
+    }
+    if (!ensure_device()) return -1;
+    return HIP_OK(bf::launch_upsample_concat(d_a, d_b, d_out, batch, h, w, ca, cb, eb, reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
+}
 int bf_upsample_concat_device(const void* d_a, const void* d_b, void* d_out, int batch, int h, int w, int ca, int cb, void* stream)
 {
-    std::lock_guard<std::mutex> lock(S().mu);
-    if (!d_a || !d_b || !d_out || batch < 1 || h < 2 || w < 2 || (h & 1) || (w & 1) || ca < 8 || cb < 8 || (ca & 7) || (cb & 7)) {
-        set_error("bf_upsample_concat_device: batch %d, %d x %d (even), %d + %d channels (multiples of 8)", batch, h, w, ca, cb);
-        return -1;
-    }
-    if (!ensure_device()) return -1;
-    return HIP_OK(bf::launch_upsample_concat(d_a, d_b, d_out, batch, h, w, ca, cb, reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
+    return upsample_concat_checked("bf_upsample_concat_device", 2, d_a, d_b, d_out, batch, h, w, ca, cb, stream);
+}
+int bf_upsample_concat_f32_device(const void* d_a, const void* d_b, void* d_out, int batch, int h, int w, int ca, int cb, void* stream)
+{
+    return upsample_concat_checked("bf_upsample_concat_f32_device", 4, d_a, d_b, d_out, batch, h, w, ca, cb, stream);
 }
 
-int bf_sppf_pool_device(void* d_buf, int batch, int h, int w, int c, void* stream)
+static int sppf_pool_checked(const char* who, int eb, void* d_buf, int batch, int h, int w, int c, void* stream)
 {
     std::lock_guard<std::mutex> lock(S().mu);
-    if (!d_buf || batch < 1 || h < 1 || w < 1 || c < 8 || (c & 7) != 0 || (long long)h * w > 2048) {
-        set_error("bf_sppf_pool_device: batch %d, %d x %d, %d channels (a multiple of 8; at most 2048 pixels per plane)", batch, h, w, c);
+    const int E = 16 / eb;
+    if (!d_buf || batch < 1 || h < 1 || w < 1 || c < E || (c % E) || (long long)h * w > 2048) {
+        set_error("%s: batch %d, %d x %d, %d channels (a multiple of %d; at most 2048 pixels per plane)", who, batch, h, w, c, E);
         return -1;
     }
     if (!ensure_device()) return -1;
-    return HIP_OK(bf::launch_sppf_pool(d_buf, batch, h, w, c, reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
+    return HIP_OK(bf::launch_sppf_pool(d_buf, batch, h, w, c, eb, reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
 }
+int bf_sppf_pool_device(void* d_buf, int batch, int h, int w, int c, void* stream) { return sppf_pool_checked("bf_sppf_pool_device", 2, d_buf, batch, h, w, c, stream); }
+int bf_sppf_pool_f32_device(void* d_buf, int batch, int h, int w, int c, void* stream) { return sppf_pool_checked("bf_sppf_pool_f32_device", 4, d_buf, batch, h, w, c, stream); }
 
+static int preprocess_checked(const char* who, int eb, const void* d_frames, void* d_out, int batch, int h, int w, int cpad, void* stream)
+{
+    std::lock_guard<std::mutex> lock(S().mu);
+    if (!d_frames || !d_out || batch < 1 || h < 1 || w < 1 || cpad < 3) { set_error("%s: batch %d, %d x %d, %d channels", who, batch, h, w, cpad); return -1; }
+    if (!ensure_device()) return -1;
+    return HIP_OK(bf::launch_preprocess_bgr8(d_frames, d_out, (long long)batch * h * w, cpad, eb, reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
+}
 int bf_preprocess_bgr8_device(const void* d_frames, void* d_out, int batch, int h, int w, int cpad, void* stream)
 {
-    std::lock_guard<std::mutex> lock(S().mu);
-    if (!d_frames || !d_out || batch < 1 || h < 1 || w < 1 || cpad < 3) { set_error("bf_preprocess_bgr8_device: batch %d, %d x %d, %d channels", batch, h, w, cpad); return -1; }
-    if (!ensure_device()) return -1;
-    return HIP_OK(bf::launch_preprocess_bgr8(d_frames, d_out, (long long)batch * h * w, cpad, reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
+    return preprocess_checked("bf_preprocess_bgr8_device", 2, d_frames, d_out, batch, h, w, cpad, stream);
+}
+int bf_preprocess_bgr8_f32_device(const void* d_frames, void* d_out, int batch, int h, int w, int cpad, void* stream)
+{
+    return preprocess_checked("bf_preprocess_bgr8_f32_device", 4, d_frames, d_out, batch, h, w, cpad, stream);
 }
 
 int bf_conv2d_weight_row(int kh, int kw, int c) { return kh > 0 && kw > 0 && c > 0 ? (kh * kw * c + 31) / 32 * 32 : -1; }
+int bf_conv2d_weight_row_f32(int kh, int kw, int c) { return kh > 0 && kw > 0 && c > 0 ? (kh * kw * c + 15) / 16 * 16 : -1; }
 
-static int conv2d_checked(const char* who, const void* d_x, const void* d_w, const float* d_bias, void* d_y, int batch, int h, int w, int c, int n, int kh, int kw,
-                          int stride, int pad, int silu, int ldy, const void* d_res, int ldr, void* stream)
+static int conv2d_checked(const char* who, int eb, const void* d_x, const void* d_w, const float* d_bias, void* d_y, int batch, int h, int w, int c, int n, int kh,
+                          int kw, int stride, int pad, int silu, int ldy, const void* d_res, int ldr, void* stream, bool cat = false, const void* d_x2 = nullptr,
+                          int c1 = 0, int ld1 = 0, int ld2 = 0, int up1 = 0)
 {
     std::lock_guard<std::mutex> lock(S().mu);
+    const int E = 16 / eb;
     if (!d_x || !d_w || !d_y) { set_error("%s: null pointer", who); return -1; }
     if (batch < 1 || h < 1 || w < 1 || n < 1 || kh < 1 || kw < 1 || stride < 1 || pad < 0 || h + 2 * pad < kh || w + 2 * pad < kw) {
         set_error("%s: batch %d, %d x %d, window %d x %d, stride %d, pad %d", who, batch, h, w, kh, kw, stride, pad);
         return -1;
     }
-    if (c < 4 || (c & (c - 1)) != 0 || ((kw * c) & 7) != 0 || (c == 4 && ((stride & 1) || (pad & 1) || (w & 1)))) {
+    if (c < 4 || (c & (c - 1)) != 0 || ((kw * c) % E) != 0 || (c < E && ((stride & 1) || (pad & 1) || (w & 1)))) {
         set_error("%s: %d input channels, window width %d, stride %d, pad %d, width %d: channels must be a power of two >= 4 with "
-                  "kw * c a multiple of 8; 4 channels need even stride, pad and width", who, c, kw, stride, pad, w);
+                  "kw * c a multiple of %d; float16 with 4 channels needs even stride, pad and width", who, c, kw, stride, pad, w, E);
         return -1;
     }
     if (ldy < n || (d_res && ldr < n)) { set_error("%s: row strides %d / %d under %d output channels", who, ldy, ldr, n); return -1; }
+    if ((reinterpret_cast<uintptr_t>(d_x) & 15) || (reinterpret_cast<uintptr_t>(d_w) & 15)) { set_error("%s: x and w must be 16-byte aligned", who); return -1; }
+    if (cat) {
+        if (c1 < E || c1 > c || (c1 % E) || (ld1 % E) || ld1 < c1 || (c1 < c && (!d_x2 || (ld2 % E) || ld2 < c - c1 || (reinterpret_cast<uintptr_t>(d_x2) & 15))) ||
+            (up1 && ((h & 1) || (w & 1)))) {
+            set_error("%s: sources of %d (pitch %d%s) + %d (pitch %d) channels for %d: whole 16-byte chunks of %d elements, 16-byte aligned; an upsampled "
+                      "source needs even h and w", who, c1, ld1, up1 ? ", upsampled" : "", c - c1, ld2, c, E);
+            return -1;
+        }
+        if (c1 == c) d_x2 = nullptr;
+    }
     if (!ensure_device()) return -1;
-    return HIP_OK(bf::launch_conv2d_nhwc_f16(d_x, d_w, d_bias, d_y, batch, h, w, c, n, kh, kw, stride, pad, silu, ldy, d_res, ldr,
-                                             reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
+    // (a plain dense source through the cat entry still takes the 1x1 path: ld1 = c selects it only when something differs -- force it with up1 / x2 / ld1)
+    return HIP_OK(bf::launch_conv2d_nhwc(eb, d_x, d_w, d_bias, d_y, batch, h, w, c, n, kh, kw, stride, pad, silu, ldy, d_res, ldr, cat ? d_x2 : nullptr,
+                                         cat ? c1 : c, cat ? ld1 : c, cat ? ld2 : 0, cat ? up1 : 0, reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
 }
 
 int bf_conv2d_nhwc_f16_device(const void* d_x, const void* d_w, const float* d_bias, void* d_y, int batch, int h, int w, int c, int n, int kh, int kw, int stride,
                               int pad, int silu, void* stream)
 {
-    return conv2d_checked("bf_conv2d_nhwc_f16_device", d_x, d_w, d_bias, d_y, batch, h, w, c, n, kh, kw, stride, pad, silu, n, nullptr, 0, stream);
+    return conv2d_checked("bf_conv2d_nhwc_f16_device", 2, d_x, d_w, d_bias, d_y, batch, h, w, c, n, kh, kw, stride, pad, silu, n, nullptr, 0, stream);
 }
 
 int bf_conv2d_nhwc_f16_into_device(const void* d_x, const void* d_w, const float* d_bias, void* d_y, int ldy, const void* d_res, int ldr, int batch, int h, int w,
                                    int c, int n, int kh, int kw, int stride, int pad, int silu, void* stream)
 {
-    return conv2d_checked("bf_conv2d_nhwc_f16_into_device", d_x, d_w, d_bias, d_y, batch, h, w, c, n, kh, kw, stride, pad, silu, ldy, d_res, ldr, stream);
+    return conv2d_checked("bf_conv2d_nhwc_f16_into_device", 2, d_x, d_w, d_bias, d_y, batch, h, w, c, n, kh, kw, stride, pad, silu, ldy, d_res, ldr, stream);
+}
+
+int bf_conv2d_nhwc_f32_device(const void* d_x, const void* d_w, const float* d_bias, void* d_y, int batch, int h, int w, int c, int n, int kh, int kw, int stride,
+                              int pad, int silu, void* stream)
+{
+    return conv2d_checked("bf_conv2d_nhwc_f32_device", 4, d_x, d_w, d_bias, d_y, batch, h, w, c, n, kh, kw, stride, pad, silu, n, nullptr, 0, stream);
+}
+
+int bf_conv2d_nhwc_f32_into_device(const void* d_x, const void* d_w, const float* d_bias, void* d_y, int ldy, const void* d_res, int ldr, int batch, int h, int w,
+                                   int c, int n, int kh, int kw, int stride, int pad, int silu, void* stream)
+{
+    return conv2d_checked("bf_conv2d_nhwc_f32_into_device", 4, d_x, d_w, d_bias, d_y, batch, h, w, c, n, kh, kw, stride, pad, silu, ldy, d_res, ldr, stream);
+}
+
+int bf_conv1x1_cat_nhwc_f16_device(const void* d_x1, int ld1, int c1, int up1, const void* d_x2, int ld2, const void* d_w, const float* d_bias, void* d_y, int ldy,
+                                   const void* d_res, int ldr, int batch, int h, int w, int c, int n, int silu, void* stream)
+{
+    return conv2d_checked("bf_conv1x1_cat_nhwc_f16_device", 2, d_x1, d_w, d_bias, d_y, batch, h, w, c, n, 1, 1, 1, 0, silu, ldy, d_res, ldr, stream, true, d_x2, c1, ld1,
+                          ld2, up1);
+}
+
+int bf_conv1x1_cat_nhwc_f32_device(const void* d_x1, int ld1, int c1, int up1, const void* d_x2, int ld2, const void* d_w, const float* d_bias, void* d_y, int ldy,
+                                   const void* d_res, int ldr, int batch, int h, int w, int c, int n, int silu, void* stream)
+{
+    return conv2d_checked("bf_conv1x1_cat_nhwc_f32_device", 4, d_x1, d_w, d_bias, d_y, batch, h, w, c, n, 1, 1, 1, 0, silu, ldy, d_res, ldr, stream, true, d_x2, c1, ld1,
+                          ld2, up1);
 }
 
 int bf_nms_device(const float* d_boxes, const float* d_scores, const int* d_cls, const int* d_counts, int batch, int k, float iou_thres, int max_det,

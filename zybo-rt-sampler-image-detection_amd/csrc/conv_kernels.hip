@@ -32,9 +32,16 @@ namespace bf {
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
-constexpr int kBM = 128, kBK = 32, kRow = kBK + 8;   // halfs per LDS row (80 bytes)
+// The element type of activations and weights: _Float16 (v_mfma_f32_32x32x16_f16) or float (v_mfma_f32_32x32x2_f32: exact f32, the
+// precision ultralytics' predict runs at by default).  Everything is laid out in 16-byte chunks of E elements.
+template <typename T> struct Elem;
+template <> struct Elem<_Float16> { static constexpr int E = 8; typedef half8 vec; };
+template <> struct Elem<float> { static constexpr int E = 4; typedef float4v vec; };
+
+constexpr int kBM = 128, kStageBytes = 64, kRowBytes = kStageBytes + 16;   // a stage is 64 bytes of K per row, rows padded to 80
 // kBN (template parameter): output channels per workgroup tile.
 //   32: layers of up to 32 channels (the 6x6 stem among them); 64; 128 for layers of 128 channels and more -- there the four waves
 //   form a 2 x 2 grid of 64-pixel x 64-channel tiles (two A and two B fragments feed four MFMAs: one LDS read per MFMA instead of 1.5,
@@ -42,78 +49,112 @@ constexpr int kBM = 128, kBK = 32, kRow = kBK + 8;   // halfs per LDS row (80 by
 
 struct ConvArgs {
     int B, H, W, C, Ho, Wo, N, KH, KW, stride, pad, act;
-    int ldy, ldr;         // halfs between consecutive pixels of the output / the residual
+    int ldy, ldr;         // elements between consecutive pixels of the output / the residual
     int wide;
-    const _Float16* res;  // optional residual, [M][ldr]
+    const void* res;      // optional residual, [M][ldr]
     int c_shift;          // log2(C)
     long long M;          // B * Ho * Wo
+    // kCat (1x1 window, stride 1, no padding, over a virtual concatenation): channels [0, c1) of a pixel come from x (ld1 elements
+    // between pixels; up1: x is [B][H/2][W/2] and read through a nearest-neighbour 2x upsampling), channels [c1, C) from x2 (ld2)
+    const void* x2;
+    int c1, ld1, ld2, up1;
 };
 
-template <int kBN>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const float* __restrict__ bias,
-                                                         _Float16* __restrict__ y, ConvArgs a)
+template <typename T, int kBN, bool kCat>
+__global__ void __launch_bounds__(256) conv_igemm_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
+                                                         T* __restrict__ y, ConvArgs a)
 {
+    typedef typename Elem<T>::vec vec;
+    constexpr int E = Elem<T>::E, kBK = kStageBytes / (int)sizeof(T), kRow = kRowBytes / (int)sizeof(T);
+    constexpr bool kF32 = sizeof(T) == 4;
     constexpr int kWN = kBN == 128 ? 2 : 1, kWM = 4 / kWN;              // the waves' grid over the tile
     constexpr int kTM = kBM / kWM / 32, kTN = kBN / kWN / 32;           // 32 x 32 MFMA tiles per wave
     constexpr int kBRows = (kBN + 63) / 64;                             // weight rows a thread moves per stage
-    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * (kBM + kBN) * kRow];
-    _Float16* const As = smem;                                          // [2][kBM][kRow]
-    _Float16* const Bs = smem + 2 * kBM * kRow;                         // [2][kBN][kRow]
+    constexpr int kCRow = kBN + E;                                      // the output tile's rows in LDS
+    constexpr int kStage = 2 * (kBM + kBN) * kRow, kTile = kBM * kCRow;
+    __shared__ __attribute__((aligned(16))) T smem[kStage > kTile ? kStage : kTile];
+    T* const As = smem;                                                 // [2][kBM][kRow]
+    T* const Bs = smem + 2 * kBM * kRow;                                // [2][kBN][kRow]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % kWM, wn = wave / kWM;
     const long long m0 = (long long)blockIdx.x * kBM;
     const int n0 = blockIdx.y * kBN;
-    // K is walked in 16-byte chunks of 8 halfs: chunk q = (kh, 8 (q % cpk) halfs into the kh run of KW * C); 4 chunks per stage
-    const int cpk = (a.KW * a.C) >> 3, n_chunk = a.KH * cpk, n_stage = (n_chunk + 3) >> 2;
+    // K is walked in 16-byte chunks of E elements: chunk q = (kh, E (q % cpk) elements into the kh run of KW * C); 4 chunks per stage
+    const int cpk = (a.KW * a.C) / E, n_chunk = a.KH * cpk, n_stage = (n_chunk + 3) >> 2;
 
     // this thread's chunks: pixel rows r and r + 64, chunk `ck` of the stage; weight rows r (+ 64), same chunk
     const int r = tid >> 2, ck = tid & 3;
     int hi0[2], wi0[2];
-    const _Float16* px[2];
+    const T* px[2];
+    const T* px2[2];
     bool pv[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const long long m = m0 + r + 64 * i;
         pv[i] = m < a.M;
-        const unsigned mm = pv[i] ? (unsigned)m : 0u;          // (M < 2^31: launch_conv2d_nhwc_f16)
-        const unsigned b = mm / (unsigned)(a.Wo * a.Ho), rem = mm - b * (unsigned)(a.Wo * a.Ho);
-        const unsigned ho = rem / (unsigned)a.Wo, wo = rem - ho * (unsigned)a.Wo;
-        hi0[i] = (int)ho * a.stride - a.pad;
-        wi0[i] = (int)wo * a.stride - a.pad;
-        px[i] = x + (size_t)b * a.H * a.W * a.C;
+        const unsigned mm = pv[i] ? (unsigned)m : 0u;          // (M < 2^31: launch_conv2d)
+        if constexpr (kCat) {
+            px2[i] = static_cast<const T*>(a.x2) + (size_t)mm * a.ld2 - a.c1;          // indexed by the channel of the concatenation
+            if (a.up1) {
+                const unsigned b = mm / (unsigned)(a.Wo * a.Ho), rem = mm - b * (unsigned)(a.Wo * a.Ho);
+                const unsigned ho = rem / (unsigned)a.Wo, wo = rem - ho * (unsigned)a.Wo;
+                px[i] = x + ((size_t)(b * (unsigned)(a.Ho >> 1) + (ho >> 1)) * (unsigned)(a.Wo >> 1) + (wo >> 1)) * a.ld1;
+            } else {
+                px[i] = x + (size_t)mm * a.ld1;
+            }
+        } else {
+            const unsigned b = mm / (unsigned)(a.Wo * a.Ho), rem = mm - b * (unsigned)(a.Wo * a.Ho);
+            const unsigned ho = rem / (unsigned)a.Wo, wo = rem - ho * (unsigned)a.Wo;
+            hi0[i] = (int)ho * a.stride - a.pad;
+            wi0[i] = (int)wo * a.stride - a.pad;
+            px[i] = x + (size_t)b * a.H * a.W * a.C;
+        }
     }
     bool wv[kBRows];
-    const _Float16* wrow[kBRows];
+    const T* wrow[kBRows];
 #pragma unroll
     for (int i = 0; i < kBRows; ++i) {
         wv[i] = r + 64 * i < kBN && n0 + r + 64 * i < a.N;
         wrow[i] = w + (size_t)(wv[i] ? n0 + r + 64 * i : 0) * n_stage * kBK;      // weight rows are padded to whole stages
     }
 
-    half8 ra[2], rb[kBRows];
+    vec ra[2], rb[kBRows];
     bool oka[2];          // (the zero padding is applied when the chunk goes to LDS: a select right behind the load would wait for it there)
     auto fetch = [&](int s) {
         const int q = 4 * s + ck;
-        const int kh = q / cpk, kk = (q - kh * cpk) << 3;      // halfs into the kh run
-        const int kw = kk >> a.c_shift, c = kk & (a.C - 1);
+        if constexpr (kCat) {
+            const int c = q * E;                               // the window is one pixel: chunk q = channels [c, c + E) of the concatenation
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int hi = hi0[i] + kh, wi = wi0[i] + kw;
-            const bool ok = pv[i] && q < n_chunk && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            const size_t off = ok ? ((size_t)hi * a.W + wi) * a.C + c : 0;
-            ra[i] = *reinterpret_cast<const half8*>(px[i] + off);
-            oka[i] = ok;
+            for (int i = 0; i < 2; ++i) {
+                const bool ok = pv[i] && q < n_chunk;
+                const T* src = c < a.c1 ? px[i] + c : px2[i] + c;
+                ra[i] = *reinterpret_cast<const vec*>(ok ? src : x);
+                oka[i] = ok;
+            }
+        } else {
+            const int kh = q / cpk, kk = (q - kh * cpk) * E;       // elements into the kh run
+            const int kw = kk >> a.c_shift, c = kk & (a.C - 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int hi = hi0[i] + kh, wi = wi0[i] + kw;
+                const bool ok = pv[i] && q < n_chunk && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                const size_t off = ok ? ((size_t)hi * a.W + wi) * a.C + c : 0;
+                ra[i] = *reinterpret_cast<const vec*>(px[i] + off);
+                oka[i] = ok;
+            }
         }
 #pragma unroll
-        for (int i = 0; i < kBRows; ++i) rb[i] = *reinterpret_cast<const half8*>(wrow[i] + (size_t)q * 8);
+        for (int i = 0; i < kBRows; ++i) rb[i] = *reinterpret_cast<const vec*>(wrow[i] + (size_t)q * E);
     };
     auto stash = [&](int buf) {
-        const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        *reinterpret_cast<half8*>(&As[(buf * kBM + r) * kRow + ck * 8]) = oka[0] ? ra[0] : z;
-        *reinterpret_cast<half8*>(&As[(buf * kBM + r + 64) * kRow + ck * 8]) = oka[1] ? ra[1] : z;
+        vec z;
+#pragma unroll
+        for (int e = 0; e < E; ++e) z[e] = 0;
+        *reinterpret_cast<vec*>(&As[(buf * kBM + r) * kRow + ck * E]) = oka[0] ? ra[0] : z;
+        *reinterpret_cast<vec*>(&As[(buf * kBM + r + 64) * kRow + ck * E]) = oka[1] ? ra[1] : z;
 #pragma unroll
         for (int i = 0; i < kBRows; ++i)
-            if (r + 64 * i < kBN) *reinterpret_cast<half8*>(&Bs[(buf * kBN + r + 64 * i) * kRow + ck * 8]) = wv[i] ? rb[i] : z;
+            if (r + 64 * i < kBN) *reinterpret_cast<vec*>(&Bs[(buf * kBN + r + 64 * i) * kRow + ck * E]) = wv[i] ? rb[i] : z;
     };
 
     float16v acc[kTM][kTN];
@@ -130,29 +171,39 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const _Float16* __restr
     for (int s = 0; s < n_stage; ++s) {
         const int buf = s & 1;
         if (s + 1 < n_stage) fetch(s + 1);                     // in flight under this stage's MFMAs
-        const _Float16* A = &As[(buf * kBM + wm * 32 * kTM + (lane & 31)) * kRow + 8 * (lane >> 5)];
-        const _Float16* Bp = &Bs[(buf * kBN + wn * 32 * kTN + (lane & 31)) * kRow + 8 * (lane >> 5)];
+        // a lane's fragment: 16 bytes of row (lane & 31) at byte 16 (lane >> 5) of each 32-byte step.  f16: the 8 halfs are the operand
+        // of one 32x32x16 MFMA.  f32: the 4 floats feed four 32x32x2 MFMAs, whose two k slots (lane halves) then hold elements
+        // e and e + 4 of the 8-deep step -- the same assignment on both operands, so each product pairs the right k.
+        const T* A = &As[(buf * kBM + wm * 32 * kTM + (lane & 31)) * kRow + E * (lane >> 5)];
+        const T* Bp = &Bs[(buf * kBN + wn * 32 * kTN + (lane & 31)) * kRow + E * (lane >> 5)];
 #pragma unroll
-        for (int k16 = 0; k16 < kBK / 16; ++k16) {
-            half8 af[kTM], bf[kTN];
+        for (int k2 = 0; k2 < 2; ++k2) {
+            vec af[kTM], bf[kTN];
 #pragma unroll
-            for (int i = 0; i < kTM; ++i) af[i] = *reinterpret_cast<const half8*>(A + 32 * i * kRow + 16 * k16);
+            for (int i = 0; i < kTM; ++i) af[i] = *reinterpret_cast<const vec*>(A + 32 * i * kRow + 2 * E * k2);
 #pragma unroll
-            for (int t = 0; t < kTN; ++t) bf[t] = *reinterpret_cast<const half8*>(Bp + 32 * t * kRow + 16 * k16);
+            for (int t = 0; t < kTN; ++t) bf[t] = *reinterpret_cast<const vec*>(Bp + 32 * t * kRow + 2 * E * k2);
+            if constexpr (kF32) {
 #pragma unroll
-            for (int i = 0; i < kTM; ++i)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int t = 0; t < kTN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[t], acc[i][t], 0, 0, 0);
+                    for (int i = 0; i < kTM; ++i)
+#pragma unroll
+                        for (int t = 0; t < kTN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[t][e], acc[i][t], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < kTM; ++i)
+#pragma unroll
+                    for (int t = 0; t < kTN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[t], acc[i][t], 0, 0, 0);
+            }
         }
         if (s + 1 < n_stage) stash(buf ^ 1);                   // the other buffer: its readers passed the previous barrier
         __syncthreads();
     }
 
-    // Epilogue.  C lane map of v_mfma_f32_32x32x16_f16: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-    // The f16 tile goes through LDS (the stage buffers are free after the loop's last barrier): rows of kBN channels + 8.
-    constexpr int kCRow = kBN + 8;
-    _Float16* Cs = smem;
-    static_assert(kBM * kCRow <= 2 * (kBM + kBN) * kRow, "the output tile fits the stage buffers");
+    // Epilogue.  C lane map of the 32x32 MFMAs: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    // The tile goes through LDS (the stage buffers are free after the loop's last barrier): rows of kBN channels + E.
+    T* Cs = smem;
 #pragma unroll
     for (int t = 0; t < kTN; ++t) {
         const int col = wn * 32 * kTN + 32 * t + (lane & 31), n = n0 + col;
@@ -162,182 +213,213 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const _Float16* __restr
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float v = acc[i][t][e] + bn;
-                if (a.act) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));      // SiLU (1 ulp reciprocal, rounded to f16 next)
-                Cs[(wm * 32 * kTM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * kCRow + col] = (_Float16)v;
+                if (a.act) {                                   // SiLU, x * sigmoid(x)
+                    if constexpr (kF32) v = v / (1.0f + expf(-v));                            // as torch's float kernel writes it
+                    else v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));                    // (1 ulp reciprocal, rounded to f16 next)
+                }
+                Cs[(wm * 32 * kTM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * kCRow + col] = (T)v;
             }
         }
     }
     __syncthreads();
-    const bool wide = a.wide != 0;                             // 16-byte stores need 16-byte rows and bases (launch_conv2d_nhwc_f16)
-    constexpr int kCC = kBN / 8;                               // 16-byte chunks per tile row
+    const bool wide = a.wide != 0;                             // 16-byte stores need 16-byte rows and bases (launch_conv2d)
+    constexpr int kCC = kBN / E;                               // 16-byte chunks per tile row
+    const T* res = static_cast<const T*>(a.res);
 #pragma unroll
     for (int j = 0; j < (kBM * kCC) / 256; ++j) {
-        const int id = tid + 256 * j, row = id / kCC, cc = (id % kCC) * 8;
+        const int id = tid + 256 * j, row = id / kCC, cc = (id % kCC) * E;
         const long long m = m0 + row;
         if (m >= a.M || n0 + cc >= a.N) continue;
-        const _Float16* src = &Cs[row * kCRow + cc];
-        _Float16* dst = y + (size_t)m * a.ldy + n0 + cc;
+        const T* src = &Cs[row * kCRow + cc];
+        T* dst = y + (size_t)m * a.ldy + n0 + cc;
         if (wide) {
-            half8 v = *reinterpret_cast<const half8*>(src);
-            if (a.res) {
-                const half8 rv = *reinterpret_cast<const half8*>(a.res + (size_t)m * a.ldr + n0 + cc);
+            vec v = *reinterpret_cast<const vec*>(src);
+            if (res) {                                         // added the way torch adds two tensors of the type: in f32, rounded once
+                const vec rv = *reinterpret_cast<const vec*>(res + (size_t)m * a.ldr + n0 + cc);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (_Float16)((float)v[e] + (float)rv[e]);
+                for (int e = 0; e < E; ++e) v[e] = (T)((float)v[e] + (float)rv[e]);
             }
-            *reinterpret_cast<half8*>(dst) = v;
+            *reinterpret_cast<vec*>(dst) = v;
         } else {
-            for (int e = 0; e < 8 && n0 + cc + e < a.N; ++e)
-                dst[e] = a.res ? (_Float16)((float)src[e] + (float)a.res[(size_t)m * a.ldr + n0 + cc + e]) : src[e];
+            for (int e = 0; e < E && n0 + cc + e < a.N; ++e)
+                dst[e] = res ? (T)((float)src[e] + (float)res[(size_t)m * a.ldr + n0 + cc + e]) : src[e];
         }
     }
 }
 
 // Camera frames -> network input (yolo_smooth_tracking.py:9-23 hands ultralytics BGR uint8 frames; its letterbox-free part is
-// BGR -> RGB, / 255): [B][H][W][3] uint8 BGR -> [B][H][W][cpad] float16 RGB in [0, 1], channels 3.. zero -- the NHWC buffer the stem
-// convolution reads.  (float)u / 255 rounded to f16: what torch computes for half(u) / 255.
-__global__ void __launch_bounds__(256) preprocess_kernel(const uint8_t* __restrict__ in, _Float16* __restrict__ out, long long pixels, int cpad)
+// BGR -> RGB, / 255): [B][H][W][3] uint8 BGR -> [B][H][W][cpad] RGB in [0, 1] (float16 or float32), channels 3.. zero -- the NHWC
+// buffer the stem convolution reads.  (float)u / 255, for float16 rounded once more: what torch computes for u.half() / 255 and u.float() / 255.
+template <typename T>
+__global__ void __launch_bounds__(256) preprocess_kernel(const uint8_t* __restrict__ in, T* __restrict__ out, long long pixels, int cpad)
 {
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += (long long)gridDim.x * blockDim.x) {
         const uint8_t* s = in + p * 3;
-        _Float16* d = out + p * cpad;
-        const _Float16 r = (_Float16)((float)s[2] / 255.0f), g = (_Float16)((float)s[1] / 255.0f), b = (_Float16)((float)s[0] / 255.0f);
+        T* d = out + p * cpad;
+        const T r = (T)((float)s[2] / 255.0f), g = (T)((float)s[1] / 255.0f), b = (T)((float)s[0] / 255.0f);
         if (cpad == 4) {
-            typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-            *reinterpret_cast<half4*>(d) = half4{r, g, b, (_Float16)0.0f};
+            typedef T vec4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<vec4*>(d) = vec4{r, g, b, (T)0.0f};
         } else {
             d[0] = r; d[1] = g; d[2] = b;
-            for (int c = 3; c < cpad; ++c) d[c] = (_Float16)0.0f;
+            for (int c = 3; c < cpad; ++c) d[c] = (T)0.0f;
         }
     }
 }
 
 // SPPF (the network's spatial-pyramid block): y1 = maxpool5(x), y2 = maxpool5(y1), y3 = maxpool5(y2), stride 1, "same" padding, written
 // next to x in the concatenation buffer [B][H][W][4c] (x = channels [0, c), written by the block's first convolution).  One workgroup
-// per (image, 8-channel chunk): the H x W x 8 plane sits in LDS (16 bytes per pixel), each pool is a row pass and a column pass.
-typedef _Float16 half8p __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ half8p max8(half8p a, half8p b)
+// per (image, 16-byte channel chunk): the H x W plane of chunks sits in LDS (16 bytes per pixel), each pool is a row pass and a column pass.
+template <typename V>
+__device__ __forceinline__ V maxv(V a, V b)
 {
-    half8p r;
+    V r;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] = a[e] > b[e] ? a[e] : b[e];
+    for (int e = 0; e < (int)(sizeof(V) / sizeof(a[0])); ++e) r[e] = a[e] > b[e] ? a[e] : b[e];
     return r;
 }
-__global__ void __launch_bounds__(256) sppf_pool_kernel(_Float16* __restrict__ buf, int H, int W, int c)
+template <typename T>
+__global__ void __launch_bounds__(256) sppf_pool_kernel(T* __restrict__ buf, int H, int W, int c)
 {
-    extern __shared__ __attribute__((aligned(16))) _Float16 plane[];          // [2][H * W] half8: current plane, row-pass result
-    half8p* cur = reinterpret_cast<half8p*>(plane);
-    half8p* tmp = cur + H * W;
-    const int chunks = c >> 3, b = blockIdx.x / chunks, ch = (blockIdx.x % chunks) * 8, ld = 4 * c, P = H * W;
-    _Float16* img = buf + (size_t)b * P * ld + ch;
-    for (int p = threadIdx.x; p < P; p += 256) cur[p] = *reinterpret_cast<const half8p*>(img + (size_t)p * ld);
+    typedef typename Elem<T>::vec vec;
+    constexpr int E = Elem<T>::E;
+    extern __shared__ __attribute__((aligned(16))) unsigned char plane[];     // [2][H * W] chunks: current plane, row-pass result
+    vec* cur = reinterpret_cast<vec*>(plane);
+    vec* tmp = cur + H * W;
+    const int chunks = c / E, b = blockIdx.x / chunks, ch = (blockIdx.x % chunks) * E, ld = 4 * c, P = H * W;
+    T* img = buf + (size_t)b * P * ld + ch;
+    for (int p = threadIdx.x; p < P; p += 256) cur[p] = *reinterpret_cast<const vec*>(img + (size_t)p * ld);
     __syncthreads();
     for (int level = 1; level <= 3; ++level) {
         for (int p = threadIdx.x; p < P; p += 256) {          // max over the row window
             const int h = p / W, w = p - h * W;
-            half8p m = cur[p];
+            vec m = cur[p];
             for (int d = 1; d <= 2; ++d) {
-                if (w - d >= 0) m = max8(m, cur[p - d]);
-                if (w + d < W) m = max8(m, cur[p + d]);
+                if (w - d >= 0) m = maxv(m, cur[p - d]);
+                if (w + d < W) m = maxv(m, cur[p + d]);
             }
             tmp[p] = m;
         }
         __syncthreads();
         for (int p = threadIdx.x; p < P; p += 256) {          // max over the column window, into the plane and the level's channel slice
             const int h = p / W;
-            half8p m = tmp[p];
+            vec m = tmp[p];
             for (int d = 1; d <= 2; ++d) {
-                if (h - d >= 0) m = max8(m, tmp[p - d * W]);
-                if (h + d < H) m = max8(m, tmp[p + d * W]);
+                if (h - d >= 0) m = maxv(m, tmp[p - d * W]);
+                if (h + d < H) m = maxv(m, tmp[p + d * W]);
             }
             cur[p] = m;       // (each thread rewrites only its own pixels of `cur`, which this pass does not read)
-            *reinterpret_cast<half8p*>(img + (size_t)p * ld + level * c) = m;
+            *reinterpret_cast<vec*>(img + (size_t)p * ld + level * c) = m;
         }
         __syncthreads();
     }
 }
 
-// The head's torch.cat((upsample2x(a), b), 1) as one pass: out[b][y][x] = (a[b][y / 2][x / 2][0..ca), b[b][y][x][0..cb)), NHWC f16, 16-byte chunks.
-__global__ void __launch_bounds__(256) upsample_concat_kernel(const _Float16* __restrict__ a, const _Float16* __restrict__ b, _Float16* __restrict__ out,
-                                                              int H, int W, int ca, int cb, long long chunks)
+// The head's torch.cat((upsample2x(a), b), 1) as one pass: out[b][y][x] = (a[b][y / 2][x / 2][0..ca), b[b][y][x][0..cb)), NHWC, 16-byte chunks
+// (cpa, cpb: chunks per pixel of a and b -- the element type does not matter to a copy).
+__global__ void __launch_bounds__(256) upsample_concat_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ out,
+                                                              int H, int W, int cpa, int cpb, long long chunks)
 {
-    const int cpa = ca >> 3, cpp = (ca + cb) >> 3;             // chunks of a pixel from a, chunks per output pixel
+    const int cpp = cpa + cpb;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (long long)gridDim.x * blockDim.x) {
         const long long pix = i / cpp;
         const int k = (int)(i - pix * cpp);
-        half8p v;
+        uint4 v;
         if (k < cpa) {
             const int x = (int)(pix % W), y = (int)((pix / W) % H);
             const long long img = pix / ((long long)W * H);
-            v = *reinterpret_cast<const half8p*>(a + ((img * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * ca + 8 * k);
+            v = a[((img * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * cpa + k];
         } else {
-            v = *reinterpret_cast<const half8p*>(b + pix * cb + 8 * (k - cpa));
+            v = b[pix * cpb + (k - cpa)];
         }
-        *reinterpret_cast<half8p*>(out + i * 8) = v;
+        out[i] = v;
     }
+}
+
+template <typename T>
+hipError_t launch_conv_t(const ConvArgs& a, const void* x, const void* w, const float* bias, void* y, bool cat, hipStream_t stream)
+{
+    const long long gx = (a.M + kBM - 1) / kBM;
+    const T* xp = static_cast<const T*>(x);
+    const T* wp = static_cast<const T*>(w);
+    T* yp = static_cast<T*>(y);
+#define BF_CONV_LAUNCH(BN, CAT) \
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BN, CAT>), dim3((unsigned)gx, (unsigned)((a.N + BN - 1) / BN)), dim3(256), 0, stream, xp, wp, bias, yp, a)
+    if (a.N >= 128) { if (cat) BF_CONV_LAUNCH(128, true); else BF_CONV_LAUNCH(128, false); }
+    else if (a.N <= 32) { if (cat) BF_CONV_LAUNCH(32, true); else BF_CONV_LAUNCH(32, false); }
+    else { if (cat) BF_CONV_LAUNCH(64, true); else BF_CONV_LAUNCH(64, false); }
+#undef BF_CONV_LAUNCH
+    return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t launch_upsample_concat(const void* a, const void* b, void* out, int B, int H, int W, int ca, int cb, hipStream_t stream)
+hipError_t launch_upsample_concat(const void* a, const void* b, void* out, int B, int H, int W, int ca, int cb, int elem_bytes, hipStream_t stream)
 {
-    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || ca < 8 || cb < 8 || (ca & 7) || (cb & 7)) return hipErrorInvalidValue;
-    const long long chunks = (long long)B * H * W * ((ca + cb) >> 3), blocks = (chunks + 255) / 256;
-    hipLaunchKernelGGL(upsample_concat_kernel, dim3((unsigned)(blocks < 262144 ? blocks : 262144)), dim3(256), 0, stream, static_cast<const _Float16*>(a),
-                       static_cast<const _Float16*>(b), static_cast<_Float16*>(out), H, W, ca, cb, chunks);
+    const int E = 16 / elem_bytes;
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || ca < E || cb < E || (ca % E) || (cb % E)) return hipErrorInvalidValue;
+    const long long chunks = (long long)B * H * W * ((ca + cb) / E), blocks = (chunks + 255) / 256;
+    hipLaunchKernelGGL(upsample_concat_kernel, dim3((unsigned)(blocks < 262144 ? blocks : 262144)), dim3(256), 0, stream, static_cast<const uint4*>(a),
+                       static_cast<const uint4*>(b), static_cast<uint4*>(out), H, W, ca / E, cb / E, chunks);
     return hipGetLastError();
 }
 
-hipError_t launch_sppf_pool(void* buf, int B, int H, int W, int c, hipStream_t stream)
+hipError_t launch_sppf_pool(void* buf, int B, int H, int W, int c, int elem_bytes, hipStream_t stream)
 {
-    if (B <= 0 || H <= 0 || W <= 0 || c < 8 || (c & 7) != 0 || (long long)H * W > 2048) return hipErrorInvalidValue;
+    const int E = 16 / elem_bytes;
+    if (B <= 0 || H <= 0 || W <= 0 || c < E || (c % E) != 0 || (long long)H * W > 2048) return hipErrorInvalidValue;
     const size_t lds = (size_t)2 * H * W * 16;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const void* fn = elem_bytes == 4 ? reinterpret_cast<const void*>(sppf_pool_kernel<float>) : reinterpret_cast<const void*>(sppf_pool_kernel<_Float16>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sppf_pool_kernel, dim3((unsigned)(B * (c >> 3))), dim3(256), lds, stream, static_cast<_Float16*>(buf), H, W, c);
+    if (elem_bytes == 4) hipLaunchKernelGGL(sppf_pool_kernel<float>, dim3((unsigned)(B * (c / E))), dim3(256), lds, stream, static_cast<float*>(buf), H, W, c);
+    else hipLaunchKernelGGL(sppf_pool_kernel<_Float16>, dim3((unsigned)(B * (c / E))), dim3(256), lds, stream, static_cast<_Float16*>(buf), H, W, c);
     return hipGetLastError();
 }
 
-hipError_t launch_preprocess_bgr8(const void* frames, void* out, long long pixels, int cpad, hipStream_t stream)
+hipError_t launch_preprocess_bgr8(const void* frames, void* out, long long pixels, int cpad, int elem_bytes, hipStream_t stream)
 {
     if (pixels <= 0 || cpad < 3) return hipErrorInvalidValue;
     const long long blocks = (pixels + 255) / 256;
-    hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream, static_cast<const uint8_t*>(frames),
-                       static_cast<_Float16*>(out), pixels, cpad);
+    const dim3 grid((unsigned)(blocks < 65536 ? blocks : 65536));
+    if (elem_bytes == 4) hipLaunchKernelGGL(preprocess_kernel<float>, grid, dim3(256), 0, stream, static_cast<const uint8_t*>(frames), static_cast<float*>(out), pixels, cpad);
+    else hipLaunchKernelGGL(preprocess_kernel<_Float16>, grid, dim3(256), 0, stream, static_cast<const uint8_t*>(frames), static_cast<_Float16*>(out), pixels, cpad);
     return hipGetLastError();
 }
 
-hipError_t launch_conv2d_nhwc_f16(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C, int N, int KH, int KW, int stride,
-                                  int pad, int act, int ldy, const void* res, int ldr, hipStream_t stream)
+// elem_bytes: 2 (float16) or 4 (float32).  x2 != nullptr or ld1 != C or up1: the 1x1 window over a virtual concatenation (ConvArgs).
+hipError_t launch_conv2d_nhwc(int elem_bytes, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C, int N, int KH, int KW,
+                              int stride, int pad, int act, int ldy, const void* res, int ldr, const void* x2, int c1, int ld1, int ld2, int up1,
+                              hipStream_t stream)
 {
+    const int E = 16 / elem_bytes;
+    if (elem_bytes != 2 && elem_bytes != 4) return hipErrorInvalidValue;
     if (ldy < N || (res && ldr < N)) return hipErrorInvalidValue;
     if (B <= 0 || H <= 0 || W <= 0 || N <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return hipErrorInvalidValue;
-    if (C < 4 || (C & (C - 1)) != 0 || ((KW * C) & 7) != 0) return hipErrorInvalidValue;       // whole 16-byte chunks per window row
-    // C = 4: a chunk is two pixels, which must leave the image together -- even window starts, even width
-    if (C == 4 && ((stride & 1) || (pad & 1) || (W & 1))) return hipErrorInvalidValue;
+    if (C < 4 || (C & (C - 1)) != 0 || ((KW * C) % E) != 0) return hipErrorInvalidValue;       // whole 16-byte chunks per window row
+    // float16, C = 4: a chunk is two pixels, which must leave the image together -- even window starts, even width
+    if (C < E && ((stride & 1) || (pad & 1) || (W & 1))) return hipErrorInvalidValue;
+    const bool cat = x2 != nullptr || up1 != 0 || ld1 != C;
+    if (cat) {
+        if (KH != 1 || KW != 1 || stride != 1 || pad != 0 || c1 < E || c1 > C || (c1 % E) || (ld1 % E) || ld1 < c1) return hipErrorInvalidValue;
+        if (c1 < C && (!x2 || (ld2 % E) || ld2 < C - c1 || (reinterpret_cast<uintptr_t>(x2) & 15))) return hipErrorInvalidValue;
+        if (up1 && ((H & 1) || (W & 1))) return hipErrorInvalidValue;
+    }
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(w) & 15)) return hipErrorInvalidValue;
     ConvArgs a;
     a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.act = act;
     a.Ho = (H + 2 * pad - KH) / stride + 1;
     a.Wo = (W + 2 * pad - KW) / stride + 1;
     if (a.Ho <= 0 || a.Wo <= 0) return hipErrorInvalidValue;
-    a.ldy = ldy; a.ldr = ldr; a.res = static_cast<const _Float16*>(res);
-    a.wide = ((N & 7) == 0 && (ldy & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
-              (!res || ((ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0))) ? 1 : 0;
+    a.ldy = ldy; a.ldr = ldr; a.res = res;
+    a.wide = ((N % E) == 0 && (ldy % E) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+              (!res || ((ldr % E) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0))) ? 1 : 0;
     a.c_shift = 0;
     while ((1 << a.c_shift) < C) ++a.c_shift;
     a.M = (long long)B * a.Ho * a.Wo;
     if (a.M > 0x7fffffffLL) return hipErrorInvalidValue;       // (the kernel splits pixel indices in 32 bits)
-    const long long gx = (a.M + kBM - 1) / kBM;
-    if (N >= 128) {
-        hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3((unsigned)gx, (unsigned)((N + 127) / 128)), dim3(256), 0, stream, static_cast<const _Float16*>(x),
-                           static_cast<const _Float16*>(w), bias, static_cast<_Float16*>(y), a);
-    } else if (N <= 32) {
-        hipLaunchKernelGGL(conv_igemm_kernel<32>, dim3((unsigned)gx, 1u), dim3(256), 0, stream, static_cast<const _Float16*>(x), static_cast<const _Float16*>(w),
-                           bias, static_cast<_Float16*>(y), a);
-    } else {
-        hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3((unsigned)gx, (unsigned)((N + 63) / 64)), dim3(256), 0, stream, static_cast<const _Float16*>(x),
-                           static_cast<const _Float16*>(w), bias, static_cast<_Float16*>(y), a);
-    }
-    return hipGetLastError();
+    a.x2 = x2; a.c1 = cat ? c1 : C; a.ld1 = cat ? ld1 : C; a.ld2 = ld2; a.up1 = up1;
+    return elem_bytes == 4 ? launch_conv_t<float>(a, x, w, bias, y, cat, stream) : launch_conv_t<_Float16>(a, x, w, bias, y, cat, stream);
 }
 
 }  // namespace bf

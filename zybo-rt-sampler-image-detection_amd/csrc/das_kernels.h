@@ -130,17 +130,21 @@ hipError_t read_phase_stamps(unsigned long long* out16, bool clear);
 
 // detector post-processing (nms_kernels.hip): YOLOv5 head decode + confidence filter, greedy NMS over score-sorted candidates
 hipError_t launch_yolo_decode(const void* const raw[3], const int hs[3], const int ws[3], const int strides[3], const float* anchors,
-                              int batch, int nc, int is_half, float conf_thres, float* d_boxes, float* d_scores, int* d_cls, hipStream_t stream);
-// out [B][H][W][ca + cb] = (nearest 2x upsampling of a [B][H/2][W/2][ca], b [B][H][W][cb]), NHWC f16 (conv_kernels.hip)
-hipError_t launch_upsample_concat(const void* a, const void* b, void* out, int B, int H, int W, int ca, int cb, hipStream_t stream);
-// SPPF pooling inside the concatenation buffer [B][H][W][4c] f16: channels [c, 4c) = the three cascaded 5x5 max pools of channels [0, c) (conv_kernels.hip)
-hipError_t launch_sppf_pool(void* buf, int B, int H, int W, int c, hipStream_t stream);
-// uint8 BGR frames [pixels][3] -> float16 RGB / 255 [pixels][cpad], channels 3.. zero (conv_kernels.hip)
-hipError_t launch_preprocess_bgr8(const void* frames, void* out, long long pixels, int cpad, hipStream_t stream);
-// Convolution + bias + optional SiLU, NHWC f16 in / out, weights [N][KH][KW][C] f16 (conv_kernels.hip).  C a power of two >= 8, KW * C a multiple of 32.
-// ldy: halfs between consecutive output pixels (>= N: the output may be a channel slice of a wider buffer); res / ldr: optional residual added to the result.
-hipError_t launch_conv2d_nhwc_f16(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C, int N, int KH, int KW, int stride,
-                                  int pad, int act, int ldy, const void* res, int ldr, hipStream_t stream);
+                              int batch, int nc, int format, float conf_thres, float* d_boxes, float* d_scores, int* d_cls, hipStream_t stream);
+// The detector's tensor kernels (conv_kernels.hip).  elem_bytes: 2 = float16, 4 = float32 activations / weights.
+// out [B][H][W][ca + cb] = (nearest 2x upsampling of a [B][H/2][W/2][ca], b [B][H][W][cb]), NHWC
+hipError_t launch_upsample_concat(const void* a, const void* b, void* out, int B, int H, int W, int ca, int cb, int elem_bytes, hipStream_t stream);
+// SPPF pooling inside the concatenation buffer [B][H][W][4c]: channels [c, 4c) = the three cascaded 5x5 max pools of channels [0, c)
+hipError_t launch_sppf_pool(void* buf, int B, int H, int W, int c, int elem_bytes, hipStream_t stream);
+// uint8 BGR frames [pixels][3] -> RGB / 255 [pixels][cpad], channels 3.. zero
+hipError_t launch_preprocess_bgr8(const void* frames, void* out, long long pixels, int cpad, int elem_bytes, hipStream_t stream);
+// Convolution + bias + optional SiLU, NHWC in / out, weights [N][KH][KW][C] in rows padded to whole 64-byte stages.  C a power of two >= 4,
+// KW * C a whole number of 16-byte chunks.  ldy: elements between consecutive output pixels (>= N: the output may be a channel slice of a
+// wider buffer); res / ldr: optional residual added to the result.  x2 / c1 / ld1 / ld2 / up1: a 1x1 window over the virtual
+// concatenation (x [.., c1) at pixel pitch ld1, optionally 2x-upsampled; x2 [c1, C) at pitch ld2) -- pass nullptr, C, C, 0, 0 otherwise.
+hipError_t launch_conv2d_nhwc(int elem_bytes, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C, int N, int KH, int KW,
+                              int stride, int pad, int act, int ldy, const void* res, int ldr, const void* x2, int c1, int ld1, int ld2, int up1,
+                              hipStream_t stream);
 hipError_t launch_topk_candidates(const float* d_scores, const float* d_boxes, const int* d_cls, int batch, int total, int K, float* d_top_scores,
                                   float* d_top_boxes, int* d_top_cls, int* d_counts, hipStream_t stream);
 hipError_t launch_nms(const float* d_boxes, const float* d_scores, const int* d_cls, const int* d_counts, int batch, int K, float iou_thres,

@@ -16,12 +16,13 @@ namespace bf {
 namespace {
 
 struct Level { const void* raw; int h, w, stride; float aw[3], ah[3]; long long box0; };
-struct DecodeArgs { Level lv[3]; int n_levels, batch, nc, total, is_half; float conf_thres; float* boxes; float* scores; int* cls; };
+struct DecodeArgs { Level lv[3]; int n_levels, batch, nc, total, is_half, nhwc; float conf_thres; float* boxes; float* scores; int* cls; };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float ld(const void* p, size_t i, int is_half) { return is_half ? __half2float(static_cast<const __half*>(p)[i]) : static_cast<const float*>(p)[i]; }
 
-// raw head output of a level: [B][3*(5+nc)][H][W] (NCHW, as the 1x1 detect convs produce it)
+// raw head output of a level: [B][3*(5+nc)][H][W] (NCHW), or with a.nhwc [B][H][W][3*(5+nc)] (the channels_last memory the detect
+// convolutions of csrc/conv_kernels.hip write: no relayout pass in between)
 __global__ void __launch_bounds__(256) decode_kernel(DecodeArgs a)
 {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -34,13 +35,14 @@ __global__ void __launch_bounds__(256) decode_kernel(DecodeArgs a)
     r -= L.box0;
     const int hw = L.h * L.w, anchor = (int)(r / hw), cell = (int)(r - (long long)anchor * hw), gy = cell / L.w, gx = cell - gy * L.w;
     const int no = 5 + a.nc;
-    const size_t base = ((size_t)b * 3 * no + (size_t)anchor * no) * hw + cell;
-    const float tx = sigmoidf_(ld(L.raw, base + 0 * (size_t)hw, a.is_half)), ty = sigmoidf_(ld(L.raw, base + 1 * (size_t)hw, a.is_half));
-    const float tw = sigmoidf_(ld(L.raw, base + 2 * (size_t)hw, a.is_half)), th = sigmoidf_(ld(L.raw, base + 3 * (size_t)hw, a.is_half));
-    const float obj = sigmoidf_(ld(L.raw, base + 4 * (size_t)hw, a.is_half));
+    const size_t base = a.nhwc ? ((size_t)b * hw + cell) * (3 * no) + (size_t)anchor * no : ((size_t)b * 3 * no + (size_t)anchor * no) * hw + cell;
+    const size_t ch = a.nhwc ? 1 : (size_t)hw;                 // elements between consecutive channels of one box
+    const float tx = sigmoidf_(ld(L.raw, base + 0 * ch, a.is_half)), ty = sigmoidf_(ld(L.raw, base + 1 * ch, a.is_half));
+    const float tw = sigmoidf_(ld(L.raw, base + 2 * ch, a.is_half)), th = sigmoidf_(ld(L.raw, base + 3 * ch, a.is_half));
+    const float obj = sigmoidf_(ld(L.raw, base + 4 * ch, a.is_half));
     float best = 0.0f; int bc = 0;
     for (int c = 0; c < a.nc; ++c) {
-        const float p = sigmoidf_(ld(L.raw, base + (size_t)(5 + c) * hw, a.is_half));
+        const float p = sigmoidf_(ld(L.raw, base + (size_t)(5 + c) * ch, a.is_half));
         if (p > best) { best = p; bc = c; }
     }
     const float cx = (tx * 2.0f - 0.5f + (float)gx) * (float)L.stride, cy = (ty * 2.0f - 0.5f + (float)gy) * (float)L.stride;
@@ -105,6 +107,7 @@ __global__ void __launch_bounds__(64) nms_scan_kernel(const float* __restrict__ 
         if (lane == 5) out[((size_t)b * max_det + kept) * 6 + 5] = (float)cls[(size_t)b * K + i];
         ++kept;
     }
+    for (int j = kept * 6 + lane; j < max_det * 6; j += 64) out[(size_t)b * max_det * 6 + j] = 0.0f;      // rows past the kept boxes: zeros
     if (lane == 0) out_count[b] = kept;
 }
 
@@ -227,8 +230,9 @@ hipError_t launch_topk_candidates(const float* d_scores, const float* d_boxes, c
 }
 
 hipError_t launch_yolo_decode(const void* const raw[3], const int hs[3], const int ws[3], const int strides[3], const float* anchors /*[3][3][2]*/,
-                              int batch, int nc, int is_half, float conf_thres, float* d_boxes, float* d_scores, int* d_cls, hipStream_t stream)
+                              int batch, int nc, int format, float conf_thres, float* d_boxes, float* d_scores, int* d_cls, hipStream_t stream)
 {
+    // format: bit 0 = float16 maps (else float32), bit 1 = NHWC maps (else NCHW)
     DecodeArgs a{};
     long long off = 0;
     for (int l = 0; l < 3; ++l) {
@@ -236,7 +240,7 @@ hipError_t launch_yolo_decode(const void* const raw[3], const int hs[3], const i
         for (int k = 0; k < 3; ++k) { a.lv[l].aw[k] = anchors[(l * 3 + k) * 2 + 0]; a.lv[l].ah[k] = anchors[(l * 3 + k) * 2 + 1]; }
         off += 3LL * hs[l] * ws[l];
     }
-    a.n_levels = 3; a.batch = batch; a.nc = nc; a.total = (int)off; a.is_half = is_half; a.conf_thres = conf_thres;
+    a.n_levels = 3; a.batch = batch; a.nc = nc; a.total = (int)off; a.is_half = format & 1; a.nhwc = (format >> 1) & 1; a.conf_thres = conf_thres;
     a.boxes = d_boxes; a.scores = d_scores; a.cls = d_cls;
     const long long n = (long long)batch * off;
     hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);

@@ -1,7 +1,7 @@
 """Mirror of the detection caller of the reference (image-detection/src/yolo_smooth_tracking.py): `yolo_model(path)
 .get_detections(frame, conf_threshold)` -> [[x1, y1, x2, y2, conf], ...] and `compute_iou`, with the network forward in
-PyTorch-ROCm -- its 60 convolutions (+ bias + SiLU) in the implicit-GEMM MFMA kernel of csrc/conv_kernels.hip -- and the head
-decode + candidate selection + NMS in the HIP kernels of csrc/nms_kernels.hip.
+PyTorch-ROCm -- its 60 convolutions (+ bias + SiLU) in the implicit-GEMM MFMA kernels of csrc/conv_kernels.hip, float32 like the
+reference's predict call or float16 -- and the head decode + candidate selection + NMS in the HIP kernels of csrc/nms_kernels.hip.
 
 `model_path` may name a state_dict saved from `image_detection.model.yolov5s.YOLOv5s`; with None (the reference's
 weights are not in its repository) a seeded random-init network is used.  SORT tracking (sort/sort.py, GPL, CPU) and the
@@ -19,24 +19,32 @@ IOU_THRES, MAX_DET, MAX_NMS = 0.45, 300, 1024
 
 
 class Detector:
-    """Batched device-resident detector: uint8/float frames already on the GPU in, [B, MAX_DET, 6] boxes + counts out."""
+    """Batched device-resident detector: uint8/float frames already on the GPU in, [B, MAX_DET, 6] boxes + counts out.
 
-    def __init__(self, model_path=None, nc=1, seed=0, device="cuda", half=True, conv_backend=None):
+    half=False (the default) is the reference's precision: `ultralytics.YOLO(...).predict(frame)` runs float32 unless told
+    otherwise (yolo_smooth_tracking.py:13-23 passes no half=).  half=True is the fast mode (float16 tensors, f32 accumulation).
+    Either way the convolutions are the library's own MFMA kernels (conv_backend "hip"; "miopen" = torch's, kept as an A/B baseline).
+
+    The buffers whose raw addresses go into kernel arguments (decode / candidate / NMS workspaces and the returned boxes / counts) are
+    allocated once per (shape, stream) and reused: a captured graph replays onto memory this object owns, and two streams never share
+    a workspace.  The tensors returned by postprocess / detect are therefore valid until the next call with the same shape on the same
+    stream -- clone them to keep them longer."""
+
+    def __init__(self, model_path=None, nc=1, seed=0, device="cuda", half=False, conv_backend=None):
         import torch
         if not torch.cuda.is_available():
             raise nat.BeamformerError("no usable HIP device; the detector has no CPU path")
         self.torch, self.device, self.half, self.nc = torch, device, half, nc
-        # conv_backend: "hip" = the library's implicit-GEMM kernel (csrc/conv_kernels.hip, float16 only; the default for half=True),
-        # "miopen" = torch's convolutions; BF_CONV_BACKEND overrides the default
-        backend = conv_backend or os.environ.get("BF_CONV_BACKEND", "hip" if half else "miopen")
+        backend = conv_backend or os.environ.get("BF_CONV_BACKEND", "hip")
         self.net = yolov5s.build(nc, seed, device, half, "miopen")
         if model_path is not None:
-            self.net.load_state_dict(torch.load(model_path, map_location=device))
+            self.net.load_state_dict(torch.load(model_path, map_location=device))      # (before the weights are repacked for the kernel)
         if backend == "hip":
             self.net = yolov5s.use_hip_convs(self.net)
         elif backend != "miopen":
             raise ValueError("conv_backend: 'miopen' or 'hip'")
         self.conv_backend = backend
+        self.dtype = torch.float16 if half else torch.float32
         self.anchors = np.ascontiguousarray(np.asarray(yolov5s.ANCHORS, dtype=np.float32).reshape(3, 3, 2))
         self._ws = {}
 
@@ -47,8 +55,9 @@ class Detector:
         if self.conv_backend == "hip" and frames_u8.dtype == t.uint8 and frames_u8.is_contiguous():
             # one kernel, straight into the 4-channel NHWC buffer the stem convolution reads (channel 3 zero)
             b, h, w, _ = frames_u8.shape
-            x = t.empty((b, 4, h, w), dtype=t.float16, device=frames_u8.device, memory_format=t.channels_last)
-            if nat.lib.bf_preprocess_bgr8_device(frames_u8.data_ptr(), x.data_ptr(), b, h, w, 4, t.cuda.current_stream().cuda_stream) != 0:
+            x = t.empty((b, 4, h, w), dtype=self.dtype, device=frames_u8.device, memory_format=t.channels_last)
+            fn = nat.lib.bf_preprocess_bgr8_device if self.half else nat.lib.bf_preprocess_bgr8_f32_device
+            if fn(frames_u8.data_ptr(), x.data_ptr(), b, h, w, 4, t.cuda.current_stream().cuda_stream) != 0:
                 nat.check()
             return x
         x = frames_u8.flip(-1).permute(0, 3, 1, 2)
@@ -56,21 +65,24 @@ class Detector:
         return x.contiguous(memory_format=t.channels_last)
 
     def raw(self, x):
+        """The three head maps as the network leaves them: [B, 3 * (5 + nc), H, W] tensors in channels_last memory."""
         with self.torch.no_grad():
-            return [o.contiguous() for o in self.net(x)]
+            return self.net(x)
 
     def postprocess(self, raw, conf_thres=CONF_LOW, iou_thres=IOU_THRES, max_det=MAX_DET):
         """Head maps -> (boxes float32 [B, max_det, 6] = x1, y1, x2, y2, conf, cls;  counts int32 [B]) on the device."""
         t = self.torch
         B = raw[0].shape[0]
+        cl = all(r.is_contiguous(memory_format=t.channels_last) for r in raw)
+        if not cl:
+            raw = [r.contiguous() for r in raw]
         hs = (C.c_int * 3)(*[int(r.shape[2]) for r in raw]); ws = (C.c_int * 3)(*[int(r.shape[3]) for r in raw])
         st = (C.c_int * 3)(*yolov5s.STRIDES)
         ptrs = (C.c_void_p * 3)(*[r.data_ptr() for r in raw])
         T = 3 * sum(int(r.shape[2]) * int(r.shape[3]) for r in raw)
         K = min(MAX_NMS, T)
-        # Workspaces whose raw addresses go into the HIP kernels' arguments are allocated once per shape and kept: a captured
-        # graph then replays onto memory this object owns, whatever the caching allocator does between replays.
-        key = (B, T, K)
+        s = t.cuda.current_stream().cuda_stream
+        key = (B, T, K, max_det, s)
         ws_ = self._ws.get(key)
         if ws_ is None:
             ws_ = self._ws[key] = dict(boxes=t.empty((B, T, 4), dtype=t.float32, device=self.device),
@@ -78,19 +90,18 @@ class Detector:
                                        cls=t.empty((B, T), dtype=t.int32, device=self.device),
                                        mask=t.empty((B, K, (K + 63) // 64), dtype=t.int64, device=self.device),
                                        top=t.empty((B, K), dtype=t.float32, device=self.device), cb=t.empty((B, K, 4), dtype=t.float32, device=self.device),
-                                       cc=t.empty((B, K), dtype=t.int32, device=self.device), counts=t.empty((B,), dtype=t.int32, device=self.device))
+                                       cc=t.empty((B, K), dtype=t.int32, device=self.device), counts=t.empty((B,), dtype=t.int32, device=self.device),
+                                       out=t.empty((B, max_det, 6), dtype=t.float32, device=self.device), n_out=t.empty((B,), dtype=t.int32, device=self.device))
         boxes, scores, cls, mask = ws_["boxes"], ws_["scores"], ws_["cls"], ws_["mask"]
-        s = t.cuda.current_stream().cuda_stream
-        is_half = 1 if raw[0].dtype == t.float16 else 0
-        if nat.lib.bf_yolo_decode_device(ptrs, hs, ws, st, nat.fptr(self.anchors), B, self.nc, is_half, conf_thres, boxes.data_ptr(),
+        fmt = (1 if raw[0].dtype == t.float16 else 0) | (2 if cl else 0)          # bit 0: float16 maps, bit 1: NHWC (channels_last) maps
+        if nat.lib.bf_yolo_decode_device(ptrs, hs, ws, st, nat.fptr(self.anchors), B, self.nc, fmt, conf_thres, boxes.data_ptr(),
                                          scores.data_ptr(), cls.data_ptr(), s) != 0:
             nat.check()
         top, cb, cc, counts = ws_["top"], ws_["cb"], ws_["cc"], ws_["counts"]
         if nat.lib.bf_topk_candidates_device(scores.data_ptr(), boxes.data_ptr(), cls.data_ptr(), B, T, K, top.data_ptr(), cb.data_ptr(), cc.data_ptr(),
                                              counts.data_ptr(), s) != 0:        # candidate order for the greedy pass
             nat.check()
-        out = t.zeros((B, max_det, 6), dtype=t.float32, device=self.device)
-        n_out = t.zeros((B,), dtype=t.int32, device=self.device)
+        out, n_out = ws_["out"], ws_["n_out"]          # (the scan kernel writes every row: kept boxes, then zeros)
         if nat.lib.bf_nms_device(cb.data_ptr(), top.data_ptr(), cc.data_ptr(), counts.data_ptr(), B, K, iou_thres, max_det, mask.data_ptr(),
                                  out.data_ptr(), n_out.data_ptr(), s) != 0:
             nat.check()

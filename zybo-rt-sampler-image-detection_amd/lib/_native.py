@@ -110,6 +110,15 @@ _sig("bf_preprocess_bgr8_device", C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_
 _sig("bf_conv2d_weight_row", C.c_int, C.c_int, C.c_int, C.c_int)
 _sig("bf_conv2d_nhwc_f16_into_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p)
 _sig("bf_conv2d_nhwc_f16_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p)
+_sig("bf_conv2d_weight_row_f32", C.c_int, C.c_int, C.c_int, C.c_int)
+_sig("bf_conv2d_nhwc_f32_into_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p)
+_sig("bf_conv2d_nhwc_f32_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p)
+_sig("bf_upsample_concat_f32_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p)
+_sig("bf_sppf_pool_f32_device", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p)
+_sig("bf_preprocess_bgr8_f32_device", C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p)
+for _n in ("bf_conv1x1_cat_nhwc_f16_device", "bf_conv1x1_cat_nhwc_f32_device"):
+    _sig(_n, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p)
 _sig("bf_topk_candidates_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 _sig("bf_nms_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 _sig("bf_jet_lut", None, C.POINTER(C.c_ubyte))

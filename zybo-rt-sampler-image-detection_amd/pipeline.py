@@ -3,7 +3,8 @@
 Per batch of B (audio window, camera frame) pairs, everything stays in HBM:
   1. delay-and-sum power maps of the B windows                      bf_das_device           (csrc/das_kernels.hip)
   2. colourise, upscale to the camera size, temporal blend, overlay  bf_heatmap_*_device     (csrc/heatmap_kernels.hip)
-  3. YOLOv5s-shaped detector on the overlaid frames                  PyTorch-ROCm (MIOpen convolutions, fp16)
+  3. YOLOv5s-shaped detector on the overlaid frames                  PyTorch-ROCm module graph, convolutions = csrc/conv_kernels.hip
+                                                                     (float32 like the reference's predict call; half=True: float16)
   4. head decode + NMS                                               bf_yolo_decode_device / bf_nms_device (csrc/nms_kernels.hip)
 In the reference these are three processes joined by queues (beamformer producer, camera reader, YOLO worker; PC/src/
 main.pyx:669-736) and the heat-map is blended onto the frame only for display (visual.py:450-455, sensorfusion/
@@ -17,13 +18,13 @@ from image_detection.src.yolo_smooth_tracking import Detector
 
 
 class FusedPipeline:
-    def __init__(self, algo="lerp", size=640, device="cuda"):
+    def __init__(self, algo="lerp", size=640, device="cuda", half=False):
         import torch
         self.torch, self.device, self.size = torch, device, size
         self.algo = {"pad": nat.PAD, "lerp": nat.LERP}[algo]
         self.mics = None
         self.stream_state = visual.HeatmapStream(size, size, device)
-        self.detector = Detector(device=device)
+        self.detector = Detector(device=device, half=half)
 
     def load_tables(self, delays, mics):
         """Steering tables once, as the reference's producer loops do before their frame loop (main.pyx:172-181)."""
