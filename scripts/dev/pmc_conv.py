@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""MFMA-pipe utilisation and shader clock of the detector's convolution kernels (dev tool; GPU box).
+
+  python3 scripts/dev/pmc_conv.py [--half] [--tag r03]   -> gpurun_out/<tag>_pmc_conv_{f32,f16}.txt  (+ the raw CSVs next to it)
+
+One rocprofv3 pass (kernel trace + SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CU_CYCLES, GRBM_GUI_ACTIVE) around scripts/conv_layer_table.py;
+per kernel template:  MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES)  (four matrix pipes per CU),
+                      clock     = GRBM_GUI_ACTIVE / 8 XCDs / duration."""
+import argparse, csv, glob, os, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ap = argparse.ArgumentParser()
+ap.add_argument("--half", action="store_true")
+ap.add_argument("--tag", default="r03")
+a = ap.parse_args()
+kind = "f16" if a.half else "f32"
+out = os.path.join(ROOT, "gpurun_out", "%s_pmc_conv_%s" % (a.tag, kind))
+cmd = ["rocprofv3", "--kernel-trace", "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE", "-d", out, "-o", "r", "--output-format", "csv", "--",
+       "python3", os.path.join(ROOT, "scripts", "conv_layer_table.py"), "--no-miopen", "--reps", "2"] + (["--half"] if a.half else [])
+rc = subprocess.call(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", timeout=500, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+if rc != 0:
+    sys.exit("rocprofv3 failed (%d)" % rc)
+cc = sorted(glob.glob(out + "/**/*counter_collection.csv", recursive=True))[-1]
+kt = sorted(glob.glob(out + "/**/*kernel_trace.csv", recursive=True))[-1]
+dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(kt))}
+agg = {}
+for r in csv.DictReader(open(cc)):
+    name = r["Kernel_Name"]
+    if "conv_igemm" not in name:
+        continue
+    short = name[name.index("conv_igemm"):].split("(")[0]
+    d = agg.setdefault(short, {"n": set(), "ns": 0})
+    if r["Dispatch_Id"] not in d["n"]:
+        d["n"].add(r["Dispatch_Id"]); d["ns"] += dur[r["Dispatch_Id"]]
+    d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+lines = ["%-46s %6s %10s %9s %9s" % ("kernel", "calls", "total ms", "MFMA busy", "clock GHz")]
+tot = {"SQ_VALU_MFMA_BUSY_CYCLES": 0.0, "SQ_BUSY_CU_CYCLES": 0.0, "GRBM_GUI_ACTIVE": 0.0, "ns": 0}
+for k, d in sorted(agg.items()):
+    lines.append("%-46s %6d %10.3f %9.3f %9.3f" % (k, len(d["n"]), d["ns"] / 1e6, d["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * d["SQ_BUSY_CU_CYCLES"]),
+                                                  d["GRBM_GUI_ACTIVE"] / 8.0 / d["ns"]))
+    for c in tot:
+        tot[c] += d[c]
+lines.append("%-46s %6s %10.3f %9.3f %9.3f" % ("all", "", tot["ns"] / 1e6, tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * tot["SQ_BUSY_CU_CYCLES"]), tot["GRBM_GUI_ACTIVE"] / 8.0 / tot["ns"]))
+txt = "\n".join(lines)
+print(txt)
+open(out + ".txt", "w").write(txt + "\n")

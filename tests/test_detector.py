@@ -202,7 +202,13 @@ def test_gpu_hip_convolution_matches_torch_fp32(native, B, C, H, W, N, k, s, p, 
         conv.bias.copy_(torch.randn(conv.bias.shape, generator=g) * 0.5)
     conv = conv.cuda().half()
     x = (torch.randn((B, C, H, W), generator=g) * 1.5).cuda().half().contiguous(memory_format=torch.channels_last)
-    got = yolov5s.HipConv(conv, silu)(x)
+    hc = yolov5s.HipConv(conv, silu)
+    got = hc(x)                                        # the default kernel: operand tiles by LDS-DMA
+    assert native.lib.bf_conv2d_use_dma_kernel(0) == 1
+    try:
+        assert torch.equal(got, hc(x))                 # the register-staged kernel: the same products in the same order
+    finally:
+        native.lib.bf_conv2d_use_dma_kernel(1)
     want = torch.nn.functional.conv2d(x.float(), conv.weight.float(), conv.bias.float(), s, p)
     if silu:
         want = torch.nn.functional.silu(want)
@@ -230,7 +236,13 @@ def test_gpu_hip_convolution_f32_matches_fp64(native, B, C, H, W, N, k, s, p, si
         want64 = torch.nn.functional.silu(want64)
     conv = conv.cuda()
     xg = x.cuda().contiguous(memory_format=torch.channels_last)
-    got = yolov5s.HipConv(conv, silu)(xg)
+    hc = yolov5s.HipConv(conv, silu)
+    got = hc(xg)                                       # the default kernel: operand tiles by LDS-DMA
+    assert native.lib.bf_conv2d_use_dma_kernel(0) == 1
+    try:
+        assert torch.equal(got, hc(xg))                # the register-staged kernel: the same products in the same order
+    finally:
+        native.lib.bf_conv2d_use_dma_kernel(1)
     want32 = torch.nn.functional.conv2d(xg, conv.weight, conv.bias, s, p)
     if silu:
         want32 = torch.nn.functional.silu(want32)
@@ -273,6 +285,17 @@ def test_gpu_hip_1x1_over_a_virtual_concatenation(native, half, up):
     assert (want.float() - ref).abs().max().item() / ref.abs().max().item() < (2e-3 if half else 1e-5)
     one = hc(full[:, : c1 + c2])                       # a single dense source through the plain entry
     assert torch.equal(one, hc(full[:, :c1], x2=full[:, c1:]))
+    # c1 = 48 channels is not a whole 64-byte stage for float16: that call ran on the register-staged kernel.  Sources that meet on a stage
+    # edge (32 + 32 channels) take the LDS-DMA kernel in both precisions: the same answer from both kernels and from the materialised tensor.
+    a2, b2 = big_a[:, 8:40], res[:, :32]
+    full2 = torch.cat((torch.nn.functional.interpolate(a2, scale_factor=2, mode="nearest") if up else a2, b2), 1).contiguous(memory_format=cl)
+    d1 = hc(a2, x2=b2, up=up)
+    assert native.lib.bf_conv2d_use_dma_kernel(0) == 1
+    try:
+        d0 = hc(a2, x2=b2, up=up)
+    finally:
+        native.lib.bf_conv2d_use_dma_kernel(1)
+    assert torch.equal(d1, d0) and torch.equal(d1, hc(full2))
     with pytest.raises(Exception):
         yolov5s.HipConv(torch.nn.Conv2d(64, 8, 3, padding=1).cuda().to(dt), True)(torch.zeros((1, 32, 4, 4), dtype=dt, device="cuda"), x2=torch.zeros((1, 32, 4, 4), dtype=dt, device="cuda"))
 
@@ -321,61 +344,86 @@ def test_gpu_network_on_hip_convolutions(native):
         assert (a.float() - c.float()).abs().max().item() / c.float().abs().max().item() < 3e-2
 
 
-def _match_boxes(a, b):
-    """Greedy one-to-one matching of two [n, 6] box lists by IoU (NumPy); returns [(i, j, iou)]."""
-    pairs = []
-    used = set()
-    for i in range(len(a)):
-        best, bj = 0.0, -1
-        for j in range(len(b)):
-            if j in used:
-                continue
-            iw = min(a[i, 2], b[j, 2]) - max(a[i, 0], b[j, 0]); ih = min(a[i, 3], b[j, 3]) - max(a[i, 1], b[j, 1])
-            inter = max(iw, 0.0) * max(ih, 0.0)
-            u = (a[i, 2] - a[i, 0]) * (a[i, 3] - a[i, 1]) + (b[j, 2] - b[j, 0]) * (b[j, 3] - b[j, 1]) - inter
-            v = inter / u if u > 0 else 0.0
-            if v > best:
-                best, bj = v, j
-        if bj >= 0:
-            used.add(bj)
-            pairs.append((i, bj, best))
-    return pairs
+def _best_partner(box, others):
+    """(index, IoU) of the box of `others` [n, 6] that overlaps `box` most."""
+    if len(others) == 0:
+        return -1, 0.0
+    iw = np.minimum(box[2], others[:, 2]) - np.maximum(box[0], others[:, 0])
+    ih = np.minimum(box[3], others[:, 3]) - np.maximum(box[1], others[:, 1])
+    inter = np.maximum(iw, 0.0) * np.maximum(ih, 0.0)
+    union = (box[2] - box[0]) * (box[3] - box[1]) + (others[:, 2] - others[:, 0]) * (others[:, 3] - others[:, 1]) - inter
+    v = np.where(union > 0, inter / np.maximum(union, 1e-30), 0.0)
+    j = int(np.argmax(v))
+    return j, float(v[j])
+
+
+def _calibrate_head(net, maps, obj_mean=-6.0, obj_std=2.5, box_std=0.5, cls_bias=8.0):
+    """Rescale the detect rows so that on the frames that produced `maps` every anchor's objectness logit is ~N(obj_mean, obj_std) over
+    the cells and the box logits ~N(0, box_std), class probability ~1: confidences spread over (0, 1) and varied boxes, as a trained
+    head gives, from a random-init trunk (the reference's weights are not in its repository)."""
+    import torch
+    with torch.no_grad():
+        for d, m in zip(net.detect, maps):
+            no = m.shape[1] // 3
+            v = m.view(m.shape[0], 3, no, m.shape[2], m.shape[3])
+            for a in range(3):
+                for r in range(5):
+                    mu, sd = v[:, a, r].mean().item(), v[:, a, r].std().item()
+                    row, b0 = a * no + r, d.bias[a * no + r].item()
+                    k = (obj_std if r == 4 else box_std) / sd
+                    d.weight[row].mul_(k)
+                    d.bias[row] = (obj_mean if r == 4 else 0.0) - k * (mu - b0)
+                d.bias[a * no + 5:(a + 1) * no] = cls_bias
+    return net
 
 
 @pytest.mark.gpu
 def test_gpu_detector_boxes_agree_across_precisions_and_backends(native):
-    """Box-level agreement (the surface yolo_smooth_tracking.py:13-23 hands its caller): seeded frames through the float32 HIP detector
-    (reference precision), torch's float32 convolutions and the float16 HIP fast mode.  float32 HIP vs float32 torch: the same boxes
-    (count equal, IoU >= 0.999, confidence within 1e-4); float16 vs float32: the same count +- 1 at conf >= 0.25, matched boxes
-    IoU >= 0.95 and confidence within 2e-2.  A random-init network fires weakly, so the detect biases are raised to get boxes to compare."""
+    """Box-level agreement on the surface yolo_smooth_tracking.py:13-23 hands its caller: seeded frames through (a) the float32 HIP
+    detector = the reference's precision, (b) the same network on torch's float32 convolutions, (c) the float16 HIP fast mode.
+    The trunk is initialised so that the image reaches the head (yolov5s.build(init_gain=1.4)) and the head is calibrated to fire on
+    ~2 % of its boxes with confidences across (0.25, 1): 110-180 boxes per 320x320 frame after NMS.
+      (a) vs (b): equal counts, every box has a partner with IoU >= 0.995 and |dconf| <= 1e-4, same class.
+      (c) vs (a): every box with conf >= 0.27 of either has a partner in the other (taken at conf >= 0.20) with IoU >= 0.95 and
+                  |dconf| <= 2e-2, up to 2 % of the boxes compared excepted: a greedy-NMS decision right at the 0.45 overlap threshold can
+                  fall the other way in float16, which keeps one box more and may suppress a neighbour of it (seen: 0 / 0 / 4 / 0 boxes
+                  of ~250 compared per frame); the counts at conf >= 0.25 differ by no more than those plus the boxes within 0.02 of 0.25."""
     import torch
+    import image_detection.model.yolov5s as Y
     from image_detection.src.yolo_smooth_tracking import Detector
     g = torch.Generator(device="cpu").manual_seed(21)
     frames = torch.randint(0, 256, (4, 320, 320, 3), dtype=torch.uint8, generator=g).cuda()
+    x = (frames.flip(-1).permute(0, 3, 1, 2).float() / 255).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        maps = Y.build(half=False, init_gain=1.4)(x)
     dets = {}
     for name, half, backend in (("f32_hip", False, "hip"), ("f32_torch", False, "miopen"), ("f16_hip", True, "hip")):
-        import image_detection.model.yolov5s as Y
-        net = Y.build(half=half)
-        with torch.no_grad():
-            for d in net.detect:                       # objectness logits up: a few hundred candidates per image survive conf 0.25
-                d.bias.view(3, -1)[:, 4] += 6.0
-                d.bias.view(3, -1)[:, 5:] += 4.0
+        net = _calibrate_head(Y.build(half=False, init_gain=1.4), maps)
+        if half:
+            net = net.half()
         det = Detector(half=half, conv_backend="miopen")
-        det.net = Y.use_hip_convs(net) if backend == "hip" else net
-        det.conv_backend = backend
-        out, n = det.detect(frames, conf_thres=0.25)
-        dets[name] = (out.cpu().numpy().copy(), n.cpu().numpy().copy())
-    o32, n32 = dets["f32_hip"]
-    assert (n32 > 0).all(), n32
-    for other, dn, iou_min, dconf in (("f32_torch", 0, 0.999, 1e-4), ("f16_hip", 1, 0.95, 2e-2)):
-        o, n = dets[other]
-        for b in range(frames.shape[0]):
-            assert abs(int(n[b]) - int(n32[b])) <= dn, (other, b, n[b], n32[b])
-            pairs = _match_boxes(o32[b, : n32[b]], o[b, : n[b]])
-            assert len(pairs) >= min(n[b], n32[b]) - dn
-            for i, j, v in pairs:
-                assert v >= iou_min, (other, b, i, j, v)
-                assert abs(o32[b, i, 4] - o[b, j, 4]) <= dconf and o32[b, i, 5] == o[b, j, 5]
+        det.net, det.conv_backend = (Y.use_hip_convs(net) if backend == "hip" else net), backend
+        out, n = det.detect(frames, conf_thres=0.20)
+        out, n = out.cpu().numpy().copy(), n.cpu().numpy().copy()
+        dets[name] = [out[b, : n[b]] for b in range(frames.shape[0])]
+    at = lambda boxes, c: boxes[boxes[:, 4] >= c]
+    for b in range(frames.shape[0]):
+        ref, tor, f16 = dets["f32_hip"][b], dets["f32_torch"][b], dets["f16_hip"][b]
+        assert 40 < len(at(ref, 0.25)) < 300, len(at(ref, 0.25))            # the calibration did what it is for (and max_det does not clip)
+        assert len(at(ref, 0.25)) == len(at(tor, 0.25))
+        for box in at(ref, 0.25):
+            j, v = _best_partner(box, tor)
+            assert v >= 0.995 and abs(box[4] - tor[j, 4]) <= 1e-4 and box[5] == tor[j, 5], (b, box, v)
+        misses = compared = 0
+        for mine, other in ((ref, f16), (f16, ref)):
+            for box in at(mine, 0.27):
+                j, v = _best_partner(box, other)
+                compared += 1
+                if not (v >= 0.95 and abs(box[4] - other[j, 4]) <= 2e-2 and box[5] == other[j, 5]):
+                    misses += 1
+        border = int(((ref[:, 4] > 0.23) & (ref[:, 4] < 0.27)).sum())
+        assert misses <= 0.02 * compared, (b, misses, compared)
+        assert abs(len(at(ref, 0.25)) - len(at(f16, 0.25))) <= misses + border, (b, len(at(ref, 0.25)), len(at(f16, 0.25)), border)
 
 
 @pytest.mark.gpu
@@ -391,7 +439,7 @@ def test_gpu_postprocess_kernels_stay_inside_their_buffers(native):
     raw = [(torch.randn((B, 3 * (5 + nc), 640 // s, 640 // s), generator=g) * 1.5).cuda() for s in yolov5s.STRIDES]
     T = 3 * sum(r.shape[2] * r.shape[3] for r in raw)
     GUARD = 1024                                       # elements of 4 bytes on either side
-    CANARY = 0x5A5AA5A5 - (1 << 32)                    # as int32
+    CANARY = 0x5A5AA5A5
 
     def guarded(n_elems, dtype):
         t = torch.full((n_elems + 2 * GUARD,), CANARY, dtype=torch.int32, device="cuda")

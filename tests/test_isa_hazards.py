@@ -83,9 +83,10 @@ def test_every_launchable_instantiation_is_scanned_and_none_that_pipelines_reads
     assert not missing, missing
     kernels, _ = chk.scan(asm)
     assert kernels == len(names)                       # the scan covered every one of them
-    pipelined = [w for w in want if "bf::copies::das_pair_kernel" in w or "bf::copies::das_long_kernel" in w or
+    pipelined = [w for w in want if "bf::copies::das_pair_kernel" in w or "bf::copies::das_long_kernel" in w or "bf::copies::das_pair2_kernel" in w or
+                 "bf::copies::das_hybrid_pair_kernel" in w or
                  (w.startswith("bf::copies::das_copies_kernel<0, 1,") or w.startswith("bf::copies::das_copies_kernel<1, 1,")) and w.endswith("false>")]
-    assert len(pipelined) == 2 + 8 + 2 * 4
+    assert len(pipelined) == 2 + 8 + 2 * 4 + 2 + 3     # (das_kernels.hip refuses to launch any of these from a build that uses scratch)
     for w in pipelined:
         m = md[short[w]]
         assert m["spill"] == 0 and m["scratch"] == 0, (w, m)

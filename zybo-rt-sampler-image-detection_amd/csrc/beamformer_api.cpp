@@ -1208,6 +1208,8 @@ int bf_preprocess_bgr8_f32_device(const void* d_frames, void* d_out, int batch, 
     return preprocess_checked("bf_preprocess_bgr8_f32_device", 4, d_frames, d_out, batch, h, w, cpad, stream);
 }
 
+int bf_conv2d_use_dma_kernel(int enable) { return bf::conv_dma_switch(enable); }
+
 int bf_conv2d_weight_row(int kh, int kw, int c) { return kh > 0 && kw > 0 && c > 0 ? (kh * kw * c + 31) / 32 * 32 : -1; }
 int bf_conv2d_weight_row_f32(int kh, int kw, int c) { return kh > 0 && kw > 0 && c > 0 ? (kh * kw * c + 15) / 16 * 16 : -1; }
 

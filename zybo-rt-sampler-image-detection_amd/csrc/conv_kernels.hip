@@ -25,6 +25,7 @@
 #include <hip/hip_fp16.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "das_kernels.h"
 
@@ -59,6 +60,17 @@ struct ConvArgs {
     const void* x2;
     int c1, ld1, ld2, up1;
 };
+
+// SiLU, x * sigmoid(x), of an f32 accumulator: exp by v_exp_f32 (2^(-x log2 e)), the reciprocal by v_rcp_f32 (1 ulp).  For a float32 layer one
+// Newton step follows (the quotient is then correct to an ulp: ~1e-7 of the value, two orders inside the 1e-5 bar the float32 path is held to);
+// a float16 result is rounded to 11 bits right after.
+__device__ __forceinline__ float silu_f(float v, bool refine)
+{
+    const float d = 1.0f + __expf(-v);
+    float r = __builtin_amdgcn_rcpf(d);
+    if (refine) r = __builtin_fmaf(r, __builtin_fmaf(-d, r, 1.0f), r);
+    return v * r;
+}
 
 template <typename T, int kBN, bool kCat>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
@@ -213,10 +225,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const T* __restrict__ x
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float v = acc[i][t][e] + bn;
-                if (a.act) {                                   // SiLU, x * sigmoid(x)
-                    if constexpr (kF32) v = v / (1.0f + expf(-v));                            // as torch's float kernel writes it
-                    else v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));                    // (1 ulp reciprocal, rounded to f16 next)
-                }
+                if (a.act) v = silu_f(v, kF32);
                 Cs[(wm * 32 * kTM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * kCRow + col] = (T)v;
             }
         }
@@ -247,16 +256,241 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const T* __restrict__ x
     }
 }
 
+// ---- The same GEMM with both operand tiles staged by LDS-DMA (buffer_load_dwordx4 ... lds: global memory -> LDS without a register hop).
+//
+// conv_igemm_kernel moves every operand global -> VGPR -> ds_write_b128 -> LDS one stage ahead; its staging stores alone cost about what
+// its MFMAs cost (profiles/r02_pmc_mfma_detector_conv.csv: matrix pipes 0.17 busy).  Here:
+//   * a ring of kDepth LDS stage buffers (64 bytes of K per row); every wave issues the 1-KiB pieces of a stage (two of the pixel tile, one or
+//     two of the weight tile) kDepth - 1 stages ahead and waits for its own with a COUNTED s_waitcnt vmcnt, so that kDepth - 2 stages of loads stay
+//     in flight across the stage's one s_barrier (raw: __syncthreads() would drain them);
+//   * an LDS-DMA piece lands lane-linear (lane l at base + 16 l), so rows cannot be padded: a 64-byte row holds its four 16-byte chunks in
+//     slots permuted by slot = chunk ^ ((row >> 2) & 3) -- applied to the SOURCE address of the lane that fills the slot and to the address of
+//     the fragment read -- which spreads the 16 rows of every ds_read_b128 lane group over all 64 banks;
+//   * the zero padding of the window, rows past the last pixel and output channels past the last are lanes whose offset is pushed past the
+//     buffer descriptor's range: the hardware returns zeros, there is no select and no branch;
+//   * (kh, position in the kh run) of a lane's chunk advance incrementally from stage to stage (no division in the loop); a 1x1 layer's
+//     offsets are its pixel's base plus 64 bytes per stage in a scalar register.
+// Operand tensors must lie below 2 GiB each (32-bit buffer offsets with the top bit as the out-of-range mark): launch_conv2d_nhwc falls
+// back to conv_igemm_kernel otherwise.
+typedef __attribute__((address_space(3))) void lds_void;
+constexpr unsigned kOob = 0x80000000u;
+
+template <int kBN> struct DmaGeo {
+    static constexpr int kDepth = 4;
+    static constexpr int kRowsPerStage = kBM + kBN;                     // 64-byte rows
+    static constexpr int kStageBytes_ = kRowsPerStage * 64;
+    static constexpr int kRingBytes = kDepth * kStageBytes_;
+    static constexpr int kBPieces = kBN == 128 ? 2 : 1;                 // weight-tile pieces per wave and stage (kBN = 32: half a piece)
+    static constexpr int kPerStage = 2 + kBPieces;                      // DMA instructions a wave issues per stage
+};
+
+template <typename T, int kBN, bool kCat>
+__global__ void __launch_bounds__(256) conv_dma_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y, ConvArgs a,
+                                                       unsigned x_bytes, unsigned x2_bytes, unsigned w_bytes)
+{
+    typedef typename Elem<T>::vec vec;
+    typedef DmaGeo<kBN> G;
+    constexpr int E = Elem<T>::E;
+    constexpr bool kF32 = sizeof(T) == 4;
+    constexpr int kWN = kBN == 128 ? 2 : 1, kWM = 4 / kWN;
+    constexpr int kTM = kBM / kWM / 32, kTN = kBN / kWN / 32;
+    constexpr int kCRow = kBN + E;
+    constexpr int kTileBytes = kBM * kCRow * (int)sizeof(T);
+    constexpr int D = G::kDepth;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G::kRingBytes > kTileBytes ? G::kRingBytes : kTileBytes];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % kWM, wn = wave / kWM;
+    const long long m0 = (long long)blockIdx.x * kBM;
+    const int n0 = blockIdx.y * kBN;
+    const int cpk = (a.KW * a.C) / E, n_chunk = a.KH * cpk, n_stage = (n_chunk + 3) >> 2;
+
+    // buffer descriptors (wave-uniform): reads past num_records return zeros
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, (int)x_bytes, 0x00020000);
+    const auto rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(kCat && a.x2 ? a.x2 : static_cast<const void*>(x)), 0, (int)(kCat && a.x2 ? x2_bytes : x_bytes), 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(w), 0, (int)w_bytes, 0x00020000);
+
+    // ---- what this lane fills.  Pixel tile: piece j of wave `wave` = chunks (2 wave + j) 64 + lane of the stage: row (2 wave + j) 16 + lane / 4,
+    // slot lane % 4, i.e. the row's chunk ck = (lane & 3) ^ ((lane >> 4) & 3) (the same for both pieces: rows 16 apart).
+    const int ck = (lane & 3) ^ ((lane >> 4) & 3);
+    unsigned abase[2];                                      // byte offset of the row's pixel (kCat: in source 1 / source 2), or kOob
+    unsigned abase2[2];
+    int hi0[2], wi0[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (2 * wave + j) * 16 + (lane >> 2);
+        const long long m = m0 + row;
+        const bool pv = m < a.M;
+        const unsigned mm = pv ? (unsigned)m : 0u;
+        abase2[j] = 0u; hi0[j] = 0; wi0[j] = 0;
+        if constexpr (kCat) {
+            unsigned p1 = mm;
+            if (a.up1) {
+                const unsigned b = mm / (unsigned)(a.Wo * a.Ho), rem = mm - b * (unsigned)(a.Wo * a.Ho);
+                const unsigned ho = rem / (unsigned)a.Wo, wo = rem - ho * (unsigned)a.Wo;
+                p1 = (b * (unsigned)(a.Ho >> 1) + (ho >> 1)) * (unsigned)(a.Wo >> 1) + (wo >> 1);
+            }
+            abase[j] = pv ? p1 * (unsigned)a.ld1 * (unsigned)sizeof(T) : kOob;
+            abase2[j] = pv ? (mm * (unsigned)a.ld2 - (unsigned)a.c1) * (unsigned)sizeof(T) : kOob;      // indexed by the channel of the concatenation
+        } else {
+            const unsigned b = mm / (unsigned)(a.Wo * a.Ho), rem = mm - b * (unsigned)(a.Wo * a.Ho);
+            const unsigned ho = rem / (unsigned)a.Wo, wo = rem - ho * (unsigned)a.Wo;
+            hi0[j] = pv ? (int)ho * a.stride - a.pad : -(1 << 28);       // (a row past the last pixel is never inside the image)
+            wi0[j] = (int)wo * a.stride - a.pad;
+            abase[j] = b * (unsigned)(a.H * a.W * a.C) * (unsigned)sizeof(T);
+        }
+    }
+    // the chunk's position in K: kh and the chunk index inside the kh run, advanced by four chunks per stage
+    int kh = ck / cpk, kk = ck - kh * cpk;
+    // Weight tile: piece j = chunks (kBPieces wave + j) 64 + lane: row (..) 16 + lane / 4 (kBN = 32: lanes 0..31 of a piece, rows wave 8 + lane / 4)
+    unsigned wbase[G::kBPieces];
+#pragma unroll
+    for (int j = 0; j < G::kBPieces; ++j) {
+        const int row = kBN == 32 ? wave * 8 + (lane >> 2) : (G::kBPieces * wave + j) * 16 + (lane >> 2);
+        const int n = n0 + row;
+        wbase[j] = n < a.N ? (unsigned)n * (unsigned)(n_stage * 64) + 16u * (unsigned)ck : kOob;     // rows are padded to whole stages
+    }
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+
+    auto issue = [&](int s) {            // the DMA pieces of stage s into ring slot s % D (past the last stage: out-of-range lanes only, zeros nobody reads)
+        const unsigned slot = lds0 + (unsigned)((s & (D - 1)) * G::kStageBytes_);
+        const bool live = s < n_stage;
+        if constexpr (kCat) {
+            const int c = (4 * s + ck) * E;                // chunk = channels [c, c + E) of the concatenation; a stage lies in one source (c1 % (4 E) == 0)
+            const bool second = 4 * s * E >= a.c1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned off = (live && 4 * s + ck < n_chunk) ? (second ? abase2[j] : abase[j]) + (unsigned)c * (unsigned)sizeof(T) : kOob;
+                lds_void* dst = (lds_void*)(size_t)(slot + (unsigned)((2 * wave + j) * 1024));
+                if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, dst, 16, off, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst, 16, off, 0, 0, 0);
+            }
+        } else {
+            const int ke = kk * E, kw = ke >> a.c_shift, c = ke & (a.C - 1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int hi = hi0[j] + kh, wi = wi0[j] + kw;
+                const bool ok = live && kh < a.KH && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                const unsigned off = ok ? abase[j] + (unsigned)((hi * a.W + wi) * a.C + c) * (unsigned)sizeof(T) : kOob;
+                lds_void* dst = (lds_void*)(size_t)(slot + (unsigned)((2 * wave + j) * 1024));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst, 16, off, 0, 0, 0);
+            }
+            kk += 4;
+            while (kk >= cpk) { kk -= cpk; ++kh; }
+        }
+#pragma unroll
+        for (int j = 0; j < G::kBPieces; ++j) {
+            const unsigned off = live ? wbase[j] + (unsigned)(s * 64) : kOob;
+            lds_void* dst = (lds_void*)(size_t)(slot + (unsigned)(kBM * 64) + (unsigned)((kBN == 32 ? wave * 512 : (G::kBPieces * wave + j) * 1024)));
+            if (kBN != 32 || lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, dst, 16, off, 0, 0, 0);
+        }
+    };
+
+    float16v acc[kTM][kTN];
+#pragma unroll
+    for (int i = 0; i < kTM; ++i)
+#pragma unroll
+        for (int t = 0; t < kTN; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][t][e] = 0.0f;
+
+    // fragment reads: row (lane & 31) of a 32-row block, logical chunk (lane >> 5) + 2 k2 -> slot ^ ((row >> 2) & 3)
+    const int sw = (lane >> 2) & 3;
+    const unsigned fa = (unsigned)((wm * 32 * kTM + (lane & 31)) * 64), fb = (unsigned)(kBM * 64 + (wn * 32 * kTN + (lane & 31)) * 64);
+    unsigned fo[2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) fo[k2] = (unsigned)((((lane >> 5) + 2 * k2) ^ sw) * 16);
+
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s) issue(s);
+    for (int s = 0; s < n_stage; ++s) {
+        // this wave's pieces of stage s have landed once at most (D - 2) younger stages' are outstanding; the barrier extends that to every wave's
+        // pieces, and says that every wave has finished reading stage s - 1, whose slot the next issue refills
+        if constexpr (D == 4) {
+            if constexpr (G::kPerStage == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        issue(s + D - 1);
+        const unsigned char* st = smem + (s & (D - 1)) * G::kStageBytes_;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            vec af[kTM], bf[kTN];
+#pragma unroll
+            for (int i = 0; i < kTM; ++i) af[i] = *reinterpret_cast<const vec*>(st + fa + 32 * 64 * i + fo[k2]);
+#pragma unroll
+            for (int t = 0; t < kTN; ++t) bf[t] = *reinterpret_cast<const vec*>(st + fb + 32 * 64 * t + fo[k2]);
+            if constexpr (kF32) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < kTM; ++i)
+#pragma unroll
+                        for (int t = 0; t < kTN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[t][e], acc[i][t], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < kTM; ++i)
+#pragma unroll
+                    for (int t = 0; t < kTN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[t], acc[i][t], 0, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the tail's dummy pieces: the ring is reused by the output tile
+    __syncthreads();
+
+    // Epilogue (as conv_igemm_kernel): bias, SiLU, the tile transposed through LDS, 16-byte stores, optional slice pitch and residual.
+    T* Cs = reinterpret_cast<T*>(smem);
+#pragma unroll
+    for (int t = 0; t < kTN; ++t) {
+        const int col = wn * 32 * kTN + 32 * t + (lane & 31), n = n0 + col;
+        const float bn = (bias && n < a.N) ? bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < kTM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[i][t][e] + bn;
+                if (a.act) v = silu_f(v, kF32);
+                Cs[(wm * 32 * kTM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * kCRow + col] = (T)v;
+            }
+        }
+    }
+    __syncthreads();
+    const bool wide = a.wide != 0;
+    constexpr int kCC = kBN / E;
+    const T* res = static_cast<const T*>(a.res);
+#pragma unroll
+    for (int j = 0; j < (kBM * kCC) / 256; ++j) {
+        const int id = tid + 256 * j, row = id / kCC, cc = (id % kCC) * E;
+        const long long m = m0 + row;
+        if (m >= a.M || n0 + cc >= a.N) continue;
+        const T* src = &Cs[row * kCRow + cc];
+        T* dst = y + (size_t)m * a.ldy + n0 + cc;
+        if (wide) {
+            vec v = *reinterpret_cast<const vec*>(src);
+            if (res) {
+                const vec rv = *reinterpret_cast<const vec*>(res + (size_t)m * a.ldr + n0 + cc);
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[e] = (T)((float)v[e] + (float)rv[e]);
+            }
+            *reinterpret_cast<vec*>(dst) = v;
+        } else {
+            for (int e = 0; e < E && n0 + cc + e < a.N; ++e)
+                dst[e] = res ? (T)((float)src[e] + (float)res[(size_t)m * a.ldr + n0 + cc + e]) : src[e];
+        }
+    }
+}
+
 // Camera frames -> network input (yolo_smooth_tracking.py:9-23 hands ultralytics BGR uint8 frames; its letterbox-free part is
 // BGR -> RGB, / 255): [B][H][W][3] uint8 BGR -> [B][H][W][cpad] RGB in [0, 1] (float16 or float32), channels 3.. zero -- the NHWC
-// buffer the stem convolution reads.  (float)u / 255, for float16 rounded once more: what torch computes for u.half() / 255 and u.float() / 255.
+// buffer the stem convolution reads.  (float)u * (1.0f / 255.0f), for float16 rounded once more: bit for bit what torch computes for u.half() / 255 and
+// u.float() / 255 on the GPU (ultralytics' `im /= 255`).
 template <typename T>
 __global__ void __launch_bounds__(256) preprocess_kernel(const uint8_t* __restrict__ in, T* __restrict__ out, long long pixels, int cpad)
 {
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += (long long)gridDim.x * blockDim.x) {
         const uint8_t* s = in + p * 3;
         T* d = out + p * cpad;
-        const T r = (T)((float)s[2] / 255.0f), g = (T)((float)s[1] / 255.0f), b = (T)((float)s[0] / 255.0f);
+        constexpr float inv = 1.0f / 255.0f;                   // torch divides a tensor by a scalar as a product with the scalar's float reciprocal
+        const T r = (T)((float)s[2] * inv), g = (T)((float)s[1] * inv), b = (T)((float)s[0] * inv);
         if (cpad == 4) {
             typedef T vec4 __attribute__((ext_vector_type(4)));
             *reinterpret_cast<vec4*>(d) = vec4{r, g, b, (T)0.0f};
@@ -337,14 +571,19 @@ __global__ void __launch_bounds__(256) upsample_concat_kernel(const uint4* __res
 }
 
 template <typename T>
-hipError_t launch_conv_t(const ConvArgs& a, const void* x, const void* w, const float* bias, void* y, bool cat, hipStream_t stream)
+hipError_t launch_conv_t(const ConvArgs& a, const void* x, const void* w, const float* bias, void* y, bool cat, bool dma, unsigned x_bytes, unsigned x2_bytes,
+                         unsigned w_bytes, hipStream_t stream)
 {
     const long long gx = (a.M + kBM - 1) / kBM;
     const T* xp = static_cast<const T*>(x);
     const T* wp = static_cast<const T*>(w);
     T* yp = static_cast<T*>(y);
-#define BF_CONV_LAUNCH(BN, CAT) \
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BN, CAT>), dim3((unsigned)gx, (unsigned)((a.N + BN - 1) / BN)), dim3(256), 0, stream, xp, wp, bias, yp, a)
+#define BF_CONV_LAUNCH(BN, CAT)                                                                                                                            \
+    do {                                                                                                                                                   \
+        const dim3 grid((unsigned)gx, (unsigned)((a.N + BN - 1) / BN));                                                                                    \
+        if (dma) hipLaunchKernelGGL((conv_dma_kernel<T, BN, CAT>), grid, dim3(256), 0, stream, xp, wp, bias, yp, a, x_bytes, x2_bytes, w_bytes);           \
+        else hipLaunchKernelGGL((conv_igemm_kernel<T, BN, CAT>), grid, dim3(256), 0, stream, xp, wp, bias, yp, a);                                         \
+    } while (0)
     if (a.N >= 128) { if (cat) BF_CONV_LAUNCH(128, true); else BF_CONV_LAUNCH(128, false); }
     else if (a.N <= 32) { if (cat) BF_CONV_LAUNCH(32, true); else BF_CONV_LAUNCH(32, false); }
     else { if (cat) BF_CONV_LAUNCH(64, true); else BF_CONV_LAUNCH(64, false); }
@@ -387,6 +626,16 @@ hipError_t launch_preprocess_bgr8(const void* frames, void* out, long long pixel
     return hipGetLastError();
 }
 
+// Which convolution kernel launch_conv2d_nhwc picks: 1 = LDS-DMA staging where its conditions hold (the default; $BF_CONV_DMA=0 changes it),
+// 0 = the register-staged kernel always.  value < 0 only reads.  Returns the previous setting.
+int conv_dma_switch(int value)
+{
+    static int state = [] { const char* e = getenv("BF_CONV_DMA"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }();
+    const int old = state;
+    if (value >= 0) state = value != 0 ? 1 : 0;
+    return old;
+}
+
 // elem_bytes: 2 (float16) or 4 (float32).  x2 != nullptr or ld1 != C or up1: the 1x1 window over a virtual concatenation (ConvArgs).
 hipError_t launch_conv2d_nhwc(int elem_bytes, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C, int N, int KH, int KW,
                               int stride, int pad, int act, int ldy, const void* res, int ldr, const void* x2, int c1, int ld1, int ld2, int up1,
@@ -419,7 +668,18 @@ hipError_t launch_conv2d_nhwc(int elem_bytes, const void* x, const void* w, cons
     a.M = (long long)B * a.Ho * a.Wo;
     if (a.M > 0x7fffffffLL) return hipErrorInvalidValue;       // (the kernel splits pixel indices in 32 bits)
     a.x2 = x2; a.c1 = cat ? c1 : C; a.ld1 = cat ? ld1 : C; a.ld2 = ld2; a.up1 = up1;
-    return elem_bytes == 4 ? launch_conv_t<float>(a, x, w, bias, y, cat, stream) : launch_conv_t<_Float16>(a, x, w, bias, y, cat, stream);
+    // The LDS-DMA kernel addresses its operands through 32-bit buffer offsets with the top bit as the out-of-range mark: every operand tensor
+    // below 2 GiB, and a two-source layer switching source on a stage boundary.  BF_CONV_DMA=0 selects the register-staged kernel (A/B runs).
+    const int want_dma = conv_dma_switch(-1);
+    const unsigned long long eb = (unsigned long long)elem_bytes;
+    const unsigned long long src1_pixels = cat && up1 ? (unsigned long long)B * (H / 2) * (W / 2) : (unsigned long long)B * H * W;
+    const unsigned long long xb = cat ? ((src1_pixels - 1) * (unsigned long long)ld1 + (unsigned long long)a.c1) * eb : src1_pixels * (unsigned long long)C * eb;
+    const unsigned long long x2b = (cat && x2) ? (((unsigned long long)B * H * W - 1) * (unsigned long long)ld2 + (unsigned long long)(C - a.c1)) * eb : 0ull;
+    const unsigned long long n_stage = ((unsigned long long)KH * ((unsigned long long)KW * C / E) + 3) / 4;
+    const unsigned long long wb = (unsigned long long)N * n_stage * 64ull;
+    const bool dma = want_dma != 0 && xb < 0x7ffffff0ull && x2b < 0x7ffffff0ull && wb < 0x7ffffff0ull && (!(cat && x2) || (a.c1 % (4 * E)) == 0);
+    return elem_bytes == 4 ? launch_conv_t<float>(a, x, w, bias, y, cat, dma, (unsigned)xb, (unsigned)x2b, (unsigned)wb, stream)
+                           : launch_conv_t<_Float16>(a, x, w, bias, y, cat, dma, (unsigned)xb, (unsigned)x2b, (unsigned)wb, stream);
 }
 
 }  // namespace bf

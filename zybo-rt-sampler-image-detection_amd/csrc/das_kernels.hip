@@ -2054,8 +2054,20 @@ __global__ void __launch_bounds__(1024, 4) das_pair2_kernel(BF_TABLE_PARAMS, KAr
         st.v0 = make_float4(0.f, 0.f, 0.f, 0.f);
         st.v1 = st.v0;
         if (4 * lane < N) {
-            st.v0 = *reinterpret_cast<const float4*>(sig0 + (size_t)mic * N + 4 * lane);
-            st.v1 = *reinterpret_cast<const float4*>(sig1 + (size_t)mic * N + 4 * lane);
+            if constexpr (kLerp) {
+                // scalar row base + one 32-bit lane offset (global_load saddr form): the per-lane 64-bit pointers of the two frames, hoisted out
+                // of the group loop, used to be spilled around the sweep (16 bytes of scratch per lane, stored once per workgroup and
+                // reloaded per group: WRITE_SIZE 5x the image bytes)
+                unsigned voff = 16u * (unsigned)lane;
+                asm volatile("" : "+v"(voff));                  // (opaque: or hipcc folds it back into two hoisted 64-bit lane pointers)
+                const char* r0 = reinterpret_cast<const char*>(sig0 + (size_t)mic * N);
+                const char* r1 = reinterpret_cast<const char*>(sig1 + (size_t)mic * N);
+                st.v0 = *reinterpret_cast<const float4*>(r0 + voff);
+                st.v1 = *reinterpret_cast<const float4*>(r1 + voff);
+            } else {
+                st.v0 = *reinterpret_cast<const float4*>(sig0 + (size_t)mic * N + 4 * lane);
+                st.v1 = *reinterpret_cast<const float4*>(sig1 + (size_t)mic * N + 4 * lane);
+            }
         }
         return st;
     };
@@ -2405,8 +2417,16 @@ __global__ void __launch_bounds__(1024, 4) das_hybrid_pair_kernel(BF_TABLE_PARAM
         st.v0 = make_float4(0.f, 0.f, 0.f, 0.f);
         st.v1 = st.v0;
         if (4 * lane < N) {
-            st.v0 = *reinterpret_cast<const float4*>(sig0 + (size_t)mic * N + 4 * lane);
-            st.v1 = *reinterpret_cast<const float4*>(sig1 + (size_t)mic * N + 4 * lane);
+            if constexpr (ALGO == ALGO_FIR_VEC) {
+                // (this flavour's eight product registers leave no room for two hoisted 64-bit lane pointers: scalar row base + one lane offset)
+                unsigned voff = 16u * (unsigned)lane;
+                asm volatile("" : "+v"(voff));
+                st.v0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sig0 + (size_t)mic * N) + voff);
+                st.v1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sig1 + (size_t)mic * N) + voff);
+            } else {
+                st.v0 = *reinterpret_cast<const float4*>(sig0 + (size_t)mic * N + 4 * lane);
+                st.v1 = *reinterpret_cast<const float4*>(sig1 + (size_t)mic * N + 4 * lane);
+            }
         }
         return st;
     };
@@ -2421,8 +2441,10 @@ __global__ void __launch_bounds__(1024, 4) das_hybrid_pair_kernel(BF_TABLE_PARAM
         c1[0] = make_float4(p0, p1, a0.x, a1.x);
         c1[1] = make_float4(a0.y, a1.y, a0.z, a1.z);
         // the zero padding after the block (hybrid_convolve_and_sum.c:98-104), 8 samples = 4 quads per copy; copy 1 still holds the last sample
+        float zf = 0.0f;
+        asm volatile("" : "+v"(zf));                            // (a zero made here: hipcc otherwise keeps a zero quad live through the sweep -- or spills it)
         if (lane == kWave - 1) {
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 z = make_float4(zf, zf, zf, zf);
             float4* t0 = reinterpret_cast<float4*>(row0 + 2 * (LEAD + 256));
             t0[0] = z; t0[1] = z; t0[2] = z; t0[3] = z;
             float4* t1 = reinterpret_cast<float4*>(row0 + RS + 2 * (LEAD + 256));
@@ -2432,7 +2454,7 @@ __global__ void __launch_bounds__(1024, 4) das_hybrid_pair_kernel(BF_TABLE_PARAM
             // the zero prefix (56 samples x 2 frames = 28 quads per copy): only the parked rows of the power pass overwrite it
             static_assert((LEAD >> 1) * C <= kWave, "one lane per prefix quad");
             constexpr int PQ = LEAD >> 1;
-            if (lane < PQ * C) reinterpret_cast<float4*>(row0 + (lane / PQ) * RS)[lane % PQ] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane < PQ * C) reinterpret_cast<float4*>(row0 + (lane / PQ) * RS)[lane % PQ] = make_float4(zf, zf, zf, zf);
         }
     };
 
@@ -2570,7 +2592,8 @@ __global__ void __launch_bounds__(1024, 4) das_hybrid_pair_kernel(BF_TABLE_PARAM
                 const float4* row4 = reinterpret_cast<const float4*>(row);
                 float sum = 0.0f;
                 int k = 0;
-                for (; k + 32 <= N; k += 32) {
+#pragma unroll 1
+                for (; k + 32 <= N; k += 32) {                  // (not unrolled further: frame 1's accumulators are live during frame 0's sum)
                     float4 v[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) v[u] = row4[(k >> 2) + u];
@@ -2856,7 +2879,7 @@ __global__ void __launch_bounds__(1024, 4) das_long_kernel(BF_TABLE_PARAMS, KArg
         const int k = min(k0 + 4 * lane, N - 4);
         st.v = *reinterpret_cast<const float4*>(src + k);
         if constexpr (kLerp) {
-            st.before = src[max(k0 - 1, 0)];
+            st.before = src[min(max(k0 - 1, 0), N - 1)];        // (clamped both ways: a segment may begin beyond a short block, N <= k0)
             st.after = src[min(k0 + 256, N - 1)];
         } else {
             // (any address for the lanes between; plain arithmetic: a nested conditional becomes two EXEC-masked branches)
@@ -3061,6 +3084,20 @@ __global__ void __launch_bounds__(1024, 4) das_long_kernel(BF_TABLE_PARAMS, KArg
 
 }  // namespace copies
 
+// The sweeps keep LDS reads in flight in hard-wired registers across asm statements: sound only in a build that does not spill
+// (tests/test_isa_hazards.py checks the build the tests run on; this checks the one that is about to launch).
+template <typename K>
+static hipError_t refuse_scratch(K kernel, int* cached)
+{
+    if (*cached < 0) {
+        hipFuncAttributes fa{};
+        hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel));
+        if (e != hipSuccess) return e;
+        *cached = (int)fa.localSizeBytes;
+    }
+    return *cached != 0 ? hipErrorInvalidDeviceFunction : hipSuccess;
+}
+
 template <int ALGO, int NC>
 hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, int frames, hipStream_t stream)
 {
@@ -3090,6 +3127,8 @@ hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, in
                         auto kernel2 = copies::das_pair2_kernel<ALGO>;
                         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
                         if (e2 != hipSuccess) return e2;
+                        static int pair2_scratch = -1;
+                        if ((e2 = refuse_scratch(kernel2, &pair2_scratch)) != hipSuccess) return e2;
                         const dim3 grid2((unsigned)plan.n_tiles * (unsigned)((frames + 1) / 2));
                         hipLaunchKernelGGL(kernel2, grid2, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole, L.tab.frac,
                                            reinterpret_cast<const float*>(L.tab.digest), a);
@@ -3121,6 +3160,8 @@ hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, in
                     auto kernel = copies::das_hybrid_pair_kernel<ALGO>;
                     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
                     if (e != hipSuccess) return e;
+                    static int hybrid_scratch = -1;
+                    if ((e = refuse_scratch(kernel, &hybrid_scratch)) != hipSuccess) return e;
                     const dim3 pair_grid((unsigned)plan.n_tiles * (unsigned)((frames + 1) / 2));
                     hipLaunchKernelGGL(kernel, pair_grid, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole,
                                        reinterpret_cast<const float*>(L.tab.digest), L.tab.taps, a);
@@ -3137,6 +3178,8 @@ hipError_t launch_nc(const DasLaunch& L, const KArgs& a, const DasPlan& plan, in
                     auto kernel = fixed_rs ? copies::das_long_kernel<ALGO, NSEG, copies::Geo<NSEG>::kRs> : copies::das_long_kernel<ALGO, NSEG, 0>;
                     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
                     if (e != hipSuccess) return e;
+                    static int long_scratch[2] = {-1, -1};
+                    if ((e = refuse_scratch(kernel, &long_scratch[fixed_rs ? 1 : 0])) != hipSuccess) return e;
                     hipLaunchKernelGGL(kernel, grid, block, plan.lds_bytes, stream, L.signals, L.images, L.mics, L.tab.whole, L.tab.frac,
                                        reinterpret_cast<const float*>(L.tab.digest), a);
                     return hipGetLastError();

@@ -238,12 +238,20 @@ def use_hip_convs(net):
     return net
 
 
-def build(nc=1, seed=0, device="cuda", half=False, conv_backend="miopen"):
+def build(nc=1, seed=0, device="cuda", half=False, conv_backend="miopen", init_gain=None):
     """Seeded random-init network, inference mode, BatchNorm folded, channels_last on the GPU; float32 (ultralytics' predict default,
     yolo_smooth_tracking.py:13-23) or float16.
-    conv_backend: "miopen" (torch's convolutions) or "hip" (this library's implicit-GEMM kernels, either precision)."""
+    conv_backend: "miopen" (torch's convolutions) or "hip" (this library's implicit-GEMM kernels, either precision).
+    init_gain: None = torch's default initialisation (activations fade with depth: the head barely sees the image); a number g draws every
+    convolution weight from N(0, (g / sqrt(fan_in))^2), which with g ~ 1.7 keeps the signal alive through the SiLU layers -- the
+    image-dependent head maps the box-level agreement tests need (tests/test_detector.py)."""
     torch.manual_seed(seed)
     net = YOLOv5s(nc)
+    if init_gain is not None:
+        for m in net.modules():
+            if isinstance(m, nn.Conv2d):
+                fan_in = m.in_channels * m.kernel_size[0] * m.kernel_size[1]
+                m.weight.data.normal_(0.0, init_gain / fan_in ** 0.5)
     for m in net.modules():                      # give BatchNorm non-trivial statistics so that folding is exercised
         if isinstance(m, nn.BatchNorm2d):
             m.running_mean.uniform_(-0.1, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.uniform_(-0.1, 0.1)
