@@ -6,7 +6,7 @@
 One rocprofv3 pass (kernel trace + SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CU_CYCLES, GRBM_GUI_ACTIVE) around scripts/conv_layer_table.py;
 per kernel template:  MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES)  (four matrix pipes per CU),
                       clock     = GRBM_GUI_ACTIVE / 8 XCDs / duration."""
-import argparse, csv, glob, os, subprocess, sys
+import argparse, csv, glob, os, re, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()
@@ -26,9 +26,13 @@ dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for
 agg = {}
 for r in csv.DictReader(open(cc)):
     name = r["Kernel_Name"]
-    if "conv_igemm" not in name:
+    m = re.search(r"conv_(dma|igemm)_kernelI(DF16_|f)((?:Li\d+E)+)Lb(\d)", name)          # (float16 instantiations come out mangled)
+    if m:
+        short = "conv_%s_kernel<%s, %s, %s>" % (m.group(1), "f16" if m.group(2) != "f" else "f32", ", ".join(re.findall(r"Li(\d+)E", m.group(3))), "cat" if m.group(4) == "1" else "plain")
+    elif "bf::" in name and "conv_" in name:
+        short = name[name.index("conv_"):].split("(")[0].replace("float", "f32").replace("true", "cat").replace("false", "plain")
+    else:
         continue
-    short = name[name.index("conv_igemm"):].split("(")[0]
     d = agg.setdefault(short, {"n": set(), "ns": 0})
     if r["Dispatch_Id"] not in d["n"]:
         d["n"].add(r["Dispatch_Id"]); d["ns"] += dur[r["Dispatch_Id"]]

@@ -275,33 +275,42 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const T* __restrict__ x
 typedef __attribute__((address_space(3))) void lds_void;
 constexpr unsigned kOob = 0x80000000u;
 
-template <int kBN> struct DmaGeo {
-    static constexpr int kDepth = 4;
-    static constexpr int kRowsPerStage = kBM + kBN;                     // 64-byte rows
-    static constexpr int kStageBytes_ = kRowsPerStage * 64;
+template <typename T, int kBM_, int kBN> struct DmaGeo {
+    // ring depth: a float32 stage carries 32 MFMAs of 64 cycles per wave (one stage of loads in flight covers the memory latency, and the smaller
+    // ring admits a third workgroup per CU); a float16 stage is 8 MFMAs of 32 cycles, so two stages stay in flight
+    static constexpr int kDepth = sizeof(T) == 4 ? 3 : 4;
+    static constexpr int kStageBytes_ = (kBM_ + kBN) * 64;              // 64-byte rows
     static constexpr int kRingBytes = kDepth * kStageBytes_;
-    static constexpr int kBPieces = kBN == 128 ? 2 : 1;                 // weight-tile pieces per wave and stage (kBN = 32: half a piece)
-    static constexpr int kPerStage = 2 + kBPieces;                      // DMA instructions a wave issues per stage
+    static constexpr int kAPieces = kBM_ / 64;                          // 1-KiB pieces (16 rows) of the pixel tile per wave and stage
+    static constexpr int kBPieces = kBN == 128 ? 2 : 1;                 // ... of the weight tile (kBN = 32: half a piece)
+    static constexpr int kPerStage = kAPieces + kBPieces;               // DMA instructions a wave issues per stage
+    // the waves' grid over the tile, 32 x 32 MFMA tiles per wave
+    static constexpr int kWN = kBN == 128 ? 2 : (kBM_ == 64 && kBN == 64 ? 2 : 1), kWM = 4 / kWN;
+    static constexpr int kTM = kBM_ / kWM / 32, kTN = kBN / kWN / 32;
+    static_assert(kTM >= 1 && kTN >= 1, "every wave owns at least one MFMA tile");
+    // the epilogue hands the tile to the stores one 32-column block per wave column at a time
+    static constexpr int kCCols = kWN * 32;
 };
 
-template <typename T, int kBN, bool kCat>
-__global__ void __launch_bounds__(256) conv_dma_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y, ConvArgs a,
-                                                       unsigned x_bytes, unsigned x2_bytes, unsigned w_bytes)
+// (The body lives in a __device__ function: the buffer-descriptor type of the LDS-DMA builtins does not exist in the host pass, and a kernel whose
+//  body the host pass cannot parse gets no launch stub; a __device__ function's host-side diagnostics are deferred and dropped.)
+template <typename T, int kBM_, int kBN, bool kCat>
+__device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y, const ConvArgs& a,
+                                              unsigned x_bytes, unsigned x2_bytes, unsigned w_bytes)
 {
     typedef typename Elem<T>::vec vec;
-    typedef DmaGeo<kBN> G;
+    typedef DmaGeo<T, kBM_, kBN> G;
     constexpr int E = Elem<T>::E;
     constexpr bool kF32 = sizeof(T) == 4;
-    constexpr int kWN = kBN == 128 ? 2 : 1, kWM = 4 / kWN;
-    constexpr int kTM = kBM / kWM / 32, kTN = kBN / kWN / 32;
-    constexpr int kCRow = kBN + E;
-    constexpr int kTileBytes = kBM * kCRow * (int)sizeof(T);
+    constexpr int kWM = G::kWM, kTM = G::kTM, kTN = G::kTN;
+    constexpr int kCRow = G::kCCols + E;
+    constexpr int kTileBytes = kBM_ * kCRow * (int)sizeof(T);
     constexpr int D = G::kDepth;
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::kRingBytes > kTileBytes ? G::kRingBytes : kTileBytes];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % kWM, wn = wave / kWM;
-    const long long m0 = (long long)blockIdx.x * kBM;
+    const long long m0 = (long long)blockIdx.x * kBM_;
     const int n0 = blockIdx.y * kBN;
     const int cpk = (a.KW * a.C) / E, n_chunk = a.KH * cpk, n_stage = (n_chunk + 3) >> 2;
 
@@ -310,15 +319,15 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(const T* __restrict__ x, 
     const auto rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(kCat && a.x2 ? a.x2 : static_cast<const void*>(x)), 0, (int)(kCat && a.x2 ? x2_bytes : x_bytes), 0x00020000);
     const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(w), 0, (int)w_bytes, 0x00020000);
 
-    // ---- what this lane fills.  Pixel tile: piece j of wave `wave` = chunks (2 wave + j) 64 + lane of the stage: row (2 wave + j) 16 + lane / 4,
-    // slot lane % 4, i.e. the row's chunk ck = (lane & 3) ^ ((lane >> 4) & 3) (the same for both pieces: rows 16 apart).
+    // ---- what this lane fills.  Pixel tile: piece j of wave `wave` = chunks (kAPieces wave + j) 64 + lane of the stage: row (..) 16 + lane / 4,
+    // slot lane % 4, i.e. the row's chunk ck = (lane & 3) ^ ((lane >> 4) & 3) (the same for every piece: their rows are multiples of 16 apart).
     const int ck = (lane & 3) ^ ((lane >> 4) & 3);
-    unsigned abase[2];                                      // byte offset of the row's pixel (kCat: in source 1 / source 2), or kOob
-    unsigned abase2[2];
-    int hi0[2], wi0[2];
+    unsigned abase[G::kAPieces];                            // byte offset of the row's pixel (kCat: in source 1 / source 2), or kOob
+    unsigned abase2[G::kAPieces];
+    int hi0[G::kAPieces], wi0[G::kAPieces];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = (2 * wave + j) * 16 + (lane >> 2);
+    for (int j = 0; j < G::kAPieces; ++j) {
+        const int row = (G::kAPieces * wave + j) * 16 + (lane >> 2);
         const long long m = m0 + row;
         const bool pv = m < a.M;
         const unsigned mm = pv ? (unsigned)m : 0u;
@@ -348,31 +357,32 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(const T* __restrict__ x, 
     for (int j = 0; j < G::kBPieces; ++j) {
         const int row = kBN == 32 ? wave * 8 + (lane >> 2) : (G::kBPieces * wave + j) * 16 + (lane >> 2);
         const int n = n0 + row;
-        wbase[j] = n < a.N ? (unsigned)n * (unsigned)(n_stage * 64) + 16u * (unsigned)ck : kOob;     // rows are padded to whole stages
+        const int ckb = (lane & 3) ^ ((row >> 2) & 3);      // (= ck except in the 32-channel tile, whose pieces are half as tall)
+        wbase[j] = n < a.N ? (unsigned)n * (unsigned)(n_stage * 64) + 16u * (unsigned)ckb : kOob;    // rows are padded to whole stages
     }
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
 
-    auto issue = [&](int s) {            // the DMA pieces of stage s into ring slot s % D (past the last stage: out-of-range lanes only, zeros nobody reads)
-        const unsigned slot = lds0 + (unsigned)((s & (D - 1)) * G::kStageBytes_);
+    auto issue = [&](int s, int ring) {   // the DMA pieces of stage s into ring slot `ring` (past the last stage: out-of-range lanes only, zeros nobody reads)
+        const unsigned slot = lds0 + (unsigned)(ring * G::kStageBytes_);
         const bool live = s < n_stage;
         if constexpr (kCat) {
             const int c = (4 * s + ck) * E;                // chunk = channels [c, c + E) of the concatenation; a stage lies in one source (c1 % (4 E) == 0)
             const bool second = 4 * s * E >= a.c1;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < G::kAPieces; ++j) {
                 const unsigned off = (live && 4 * s + ck < n_chunk) ? (second ? abase2[j] : abase[j]) + (unsigned)c * (unsigned)sizeof(T) : kOob;
-                lds_void* dst = (lds_void*)(size_t)(slot + (unsigned)((2 * wave + j) * 1024));
+                lds_void* dst = (lds_void*)(size_t)(slot + (unsigned)((G::kAPieces * wave + j) * 1024));
                 if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, dst, 16, off, 0, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst, 16, off, 0, 0, 0);
             }
         } else {
             const int ke = kk * E, kw = ke >> a.c_shift, c = ke & (a.C - 1);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < G::kAPieces; ++j) {
                 const int hi = hi0[j] + kh, wi = wi0[j] + kw;
                 const bool ok = live && kh < a.KH && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
                 const unsigned off = ok ? abase[j] + (unsigned)((hi * a.W + wi) * a.C + c) * (unsigned)sizeof(T) : kOob;
-                lds_void* dst = (lds_void*)(size_t)(slot + (unsigned)((2 * wave + j) * 1024));
+                lds_void* dst = (lds_void*)(size_t)(slot + (unsigned)((G::kAPieces * wave + j) * 1024));
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst, 16, off, 0, 0, 0);
             }
             kk += 4;
@@ -381,7 +391,7 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int j = 0; j < G::kBPieces; ++j) {
             const unsigned off = live ? wbase[j] + (unsigned)(s * 64) : kOob;
-            lds_void* dst = (lds_void*)(size_t)(slot + (unsigned)(kBM * 64) + (unsigned)((kBN == 32 ? wave * 512 : (G::kBPieces * wave + j) * 1024)));
+            lds_void* dst = (lds_void*)(size_t)(slot + (unsigned)(kBM_ * 64) + (unsigned)((kBN == 32 ? wave * 512 : (G::kBPieces * wave + j) * 1024)));
             if (kBN != 32 || lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, dst, 16, off, 0, 0, 0);
         }
     };
@@ -396,22 +406,29 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(const T* __restrict__ x, 
 
     // fragment reads: row (lane & 31) of a 32-row block, logical chunk (lane >> 5) + 2 k2 -> slot ^ ((row >> 2) & 3)
     const int sw = (lane >> 2) & 3;
-    const unsigned fa = (unsigned)((wm * 32 * kTM + (lane & 31)) * 64), fb = (unsigned)(kBM * 64 + (wn * 32 * kTN + (lane & 31)) * 64);
+    const unsigned fa = (unsigned)((wm * 32 * kTM + (lane & 31)) * 64), fb = (unsigned)(kBM_ * 64 + (wn * 32 * kTN + (lane & 31)) * 64);
     unsigned fo[2];
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) fo[k2] = (unsigned)((((lane >> 5) + 2 * k2) ^ sw) * 16);
 
 #pragma unroll
-    for (int s = 0; s < D - 1; ++s) issue(s);
+    for (int s = 0; s < D - 1; ++s) issue(s, s);
+    int rd = 0, wr = D - 1;                                   // ring slots: stage s is read from rd, stage s + D - 1 goes to wr (= the slot stage s - 1 left)
     for (int s = 0; s < n_stage; ++s) {
         // this wave's pieces of stage s have landed once at most (D - 2) younger stages' are outstanding; the barrier extends that to every wave's
         // pieces, and says that every wave has finished reading stage s - 1, whose slot the next issue refills
-        if constexpr (D == 4) {
-            if constexpr (G::kPerStage == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        }
+        constexpr int kInFlight = (D - 2) * G::kPerStage;
+        static_assert(kInFlight == 2 || kInFlight == 3 || kInFlight == 4 || kInFlight == 6 || kInFlight == 8, "a wait instruction per count");
+        if constexpr (kInFlight == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if constexpr (kInFlight == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        if constexpr (kInFlight == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr (kInFlight == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if constexpr (kInFlight == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        issue(s + D - 1);
-        const unsigned char* st = smem + (s & (D - 1)) * G::kStageBytes_;
+        issue(s + D - 1, wr);
+        const unsigned char* st = smem + rd * G::kStageBytes_;
+        rd = rd + 1 == D ? 0 : rd + 1;
+        wr = wr + 1 == D ? 0 : wr + 1;
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             vec af[kTM], bf[kTN];
@@ -435,48 +452,60 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(const T* __restrict__ x, 
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the tail's dummy pieces: the ring is reused by the output tile
-    __syncthreads();
 
-    // Epilogue (as conv_igemm_kernel): bias, SiLU, the tile transposed through LDS, 16-byte stores, optional slice pitch and residual.
+    // Epilogue: bias, SiLU, the tile transposed through LDS, 16-byte stores, optional slice pitch and residual.  One pass per MFMA tile column of a
+    // wave (kTN passes): the LDS image of a pass is kBM rows of the kWN waves' 32 columns each, so that it never outgrows the ring.
     T* Cs = reinterpret_cast<T*>(smem);
-#pragma unroll
-    for (int t = 0; t < kTN; ++t) {
-        const int col = wn * 32 * kTN + 32 * t + (lane & 31), n = n0 + col;
-        const float bn = (bias && n < a.N) ? bias[n] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < kTM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = acc[i][t][e] + bn;
-                if (a.act) v = silu_f(v, kF32);
-                Cs[(wm * 32 * kTM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * kCRow + col] = (T)v;
-            }
-        }
-    }
-    __syncthreads();
     const bool wide = a.wide != 0;
-    constexpr int kCC = kBN / E;
+    constexpr int kCC = G::kCCols / E;                         // 16-byte chunks per row of a pass
     const T* res = static_cast<const T*>(a.res);
 #pragma unroll
-    for (int j = 0; j < (kBM * kCC) / 256; ++j) {
-        const int id = tid + 256 * j, row = id / kCC, cc = (id % kCC) * E;
-        const long long m = m0 + row;
-        if (m >= a.M || n0 + cc >= a.N) continue;
-        const T* src = &Cs[row * kCRow + cc];
-        T* dst = y + (size_t)m * a.ldy + n0 + cc;
-        if (wide) {
-            vec v = *reinterpret_cast<const vec*>(src);
-            if (res) {
-                const vec rv = *reinterpret_cast<const vec*>(res + (size_t)m * a.ldr + n0 + cc);
+    for (int t = 0; t < kTN; ++t) {
+        __syncthreads();                                       // the stage buffers (pass 0) / the previous pass's image have been read
+        {
+            const int col = wn * 32 + (lane & 31), n = n0 + wn * 32 * kTN + 32 * t + (lane & 31);
+            const float bn = (bias && n < a.N) ? bias[n] : 0.0f;
 #pragma unroll
-                for (int e = 0; e < E; ++e) v[e] = (T)((float)v[e] + (float)rv[e]);
+            for (int i = 0; i < kTM; ++i) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = acc[i][t][e] + bn;
+                    if (a.act) v = silu_f(v, kF32);
+                    Cs[(wm * 32 * kTM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * kCRow + col] = (T)v;
+                }
             }
-            *reinterpret_cast<vec*>(dst) = v;
-        } else {
-            for (int e = 0; e < E && n0 + cc + e < a.N; ++e)
-                dst[e] = res ? (T)((float)src[e] + (float)res[(size_t)m * a.ldr + n0 + cc + e]) : src[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < (kBM_ * kCC + 255) / 256; ++j) {
+            const int id = tid + 256 * j, row = id / kCC, cq = id % kCC;
+            const int wcol = (cq * E) / 32, cin = (cq * E) % 32;       // the wave column the chunk came from, its place in that wave's 32 columns
+            const int nn = n0 + wcol * 32 * kTN + 32 * t + cin;         // first output channel of the chunk
+            const long long m = m0 + row;
+            if (row >= kBM_ || m >= a.M || nn >= a.N) continue;
+            const T* src = &Cs[row * kCRow + cq * E];
+            T* dst = y + (size_t)m * a.ldy + nn;
+            if (wide) {
+                vec v = *reinterpret_cast<const vec*>(src);
+                if (res) {
+                    const vec rv = *reinterpret_cast<const vec*>(res + (size_t)m * a.ldr + nn);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) v[e] = (T)((float)v[e] + (float)rv[e]);
+                }
+                *reinterpret_cast<vec*>(dst) = v;
+            } else {
+                for (int e = 0; e < E && nn + e < a.N; ++e)
+                    dst[e] = res ? (T)((float)src[e] + (float)res[(size_t)m * a.ldr + nn + e]) : src[e];
+            }
         }
     }
+}
+
+template <typename T, int kBM_, int kBN, bool kCat>
+__global__ void __launch_bounds__(256) conv_dma_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y, ConvArgs a,
+                                                       unsigned x_bytes, unsigned x2_bytes, unsigned w_bytes)
+{
+    conv_dma_body<T, kBM_, kBN, kCat>(x, w, bias, y, a, x_bytes, x2_bytes, w_bytes);
 }
 
 // Camera frames -> network input (yolo_smooth_tracking.py:9-23 hands ultralytics BGR uint8 frames; its letterbox-free part is
@@ -570,20 +599,57 @@ __global__ void __launch_bounds__(256) upsample_concat_kernel(const uint4* __res
     }
 }
 
+// Tile of the LDS-DMA kernel for a layer.  A launch lasts as long as its most loaded CU, i.e. ceil(workgroups / CUs) tiles' worth of matrix work
+// (tile area x K is the same product whatever the shape), so among the shapes the output allows the one with the least
+// ceil(workgroups / CUs) x area x (1 + thin / rows + thin / columns) wins.  `thin` prices what a smaller tile moves per MFMA: almost nothing
+// next to a 64-cycle float32 MFMA (profiles/r03_conv_layers_f32.csv: 64 x 64 tiles win on most layers through the finer split alone), a lot next
+// to a float16 one, whose 128 x 128 tile already keeps the LDS port 3/4 busy (measured: 64 x 64 tiles there run at 0.15 of the matrix peak).
+struct DmaTile { int bm, bn; };
+inline DmaTile pick_dma_tile(long long M, int N, int n_cus, bool f32)
+{
+    static const DmaTile shapes[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 32}};
+    const double thin = f32 ? 8.0 : 160.0;
+    DmaTile best{128, N >= 128 ? 128 : (N <= 32 ? 32 : 64)};
+    double best_cost = 1e300;
+    for (const DmaTile& t : shapes) {
+        if (t.bn == 32 ? N > 32 : N <= 32) continue;           // 32-channel tiles for layers of up to 32 channels, and only for those
+        const long long wgs = ((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
+        const double cost = (double)((wgs + n_cus - 1) / n_cus) * t.bm * t.bn * (1.0 + thin / t.bm + thin / t.bn);
+        if (cost < best_cost) { best_cost = cost; best = t; }
+    }
+    return best;
+}
+
 template <typename T>
 hipError_t launch_conv_t(const ConvArgs& a, const void* x, const void* w, const float* bias, void* y, bool cat, bool dma, unsigned x_bytes, unsigned x2_bytes,
                          unsigned w_bytes, hipStream_t stream)
 {
-    const long long gx = (a.M + kBM - 1) / kBM;
     const T* xp = static_cast<const T*>(x);
     const T* wp = static_cast<const T*>(w);
     T* yp = static_cast<T*>(y);
-#define BF_CONV_LAUNCH(BN, CAT)                                                                                                                            \
-    do {                                                                                                                                                   \
-        const dim3 grid((unsigned)gx, (unsigned)((a.N + BN - 1) / BN));                                                                                    \
-        if (dma) hipLaunchKernelGGL((conv_dma_kernel<T, BN, CAT>), grid, dim3(256), 0, stream, xp, wp, bias, yp, a, x_bytes, x2_bytes, w_bytes);           \
-        else hipLaunchKernelGGL((conv_igemm_kernel<T, BN, CAT>), grid, dim3(256), 0, stream, xp, wp, bias, yp, a);                                         \
-    } while (0)
+    if (dma) {
+        static int n_cus = 0;
+        if (n_cus == 0) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cus = v; else n_cus = 256;
+        }
+        const DmaTile t = pick_dma_tile(a.M, a.N, n_cus, sizeof(T) == 4);
+#define BF_DMA_LAUNCH(BM, BN, CAT)                                                                                                                         \
+        hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, CAT>), dim3((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN)), dim3(256), 0, stream,  \
+                           xp, wp, bias, yp, a, x_bytes, x2_bytes, w_bytes)
+#define BF_DMA_PICK(BM, BN) do { if (cat) BF_DMA_LAUNCH(BM, BN, true); else BF_DMA_LAUNCH(BM, BN, false); } while (0)
+        if (t.bm == 128 && t.bn == 128) BF_DMA_PICK(128, 128);
+        else if (t.bm == 128 && t.bn == 64) BF_DMA_PICK(128, 64);
+        else if (t.bm == 128) BF_DMA_PICK(128, 32);
+        else if (t.bn == 128) BF_DMA_PICK(64, 128);
+        else BF_DMA_PICK(64, 64);
+#undef BF_DMA_PICK
+#undef BF_DMA_LAUNCH
+        return hipGetLastError();
+    }
+    const long long gx = (a.M + kBM - 1) / kBM;
+#define BF_CONV_LAUNCH(BN, CAT) \
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BN, CAT>), dim3((unsigned)gx, (unsigned)((a.N + BN - 1) / BN)), dim3(256), 0, stream, xp, wp, bias, yp, a)
     if (a.N >= 128) { if (cat) BF_CONV_LAUNCH(128, true); else BF_CONV_LAUNCH(128, false); }
     else if (a.N <= 32) { if (cat) BF_CONV_LAUNCH(32, true); else BF_CONV_LAUNCH(32, false); }
     else { if (cat) BF_CONV_LAUNCH(64, true); else BF_CONV_LAUNCH(64, false); }
