@@ -85,9 +85,9 @@ def fold_extras(a):
     agg = {}
     for r in csv.DictReader(open(_one(base % "pmc_mfma" + "/**/*counter_collection.csv"))):
         name = r["Kernel_Name"]
-        if "bf::" not in name:
+        if "bf::" not in name and "_ZN2bf" not in name:
             continue
-        short = name[name.index("bf::"):].split("(")[0]
+        short = short_name(name)
         d = agg.setdefault(short, {"ids": set(), "ns": 0})
         if r["Dispatch_Id"] not in d["ids"]:
             d["ids"].add(r["Dispatch_Id"]); d["ns"] += kt[r["Dispatch_Id"]]
@@ -104,6 +104,20 @@ def fold_extras(a):
     if os.path.exists(src):
         open(os.path.join(prof, "%s_bench_default_with_extras.json" % a.tag), "w").write(open(src).read())
     print("folded extras of", a.tag)
+
+
+def short_name(name):
+    """A readable kernel name: the template instance without namespaces and argument lists (rocprofv3 leaves _Float16 instantiations mangled)."""
+    import re
+    m = re.search(r"conv_(dma|igemm)_kernelI(DF16_|f)((?:Li\d+E)+)Lb(\d)", name)
+    if m:
+        return "conv_%s_kernel<%s, %s, %s>" % (m.group(1), "f16" if m.group(2) != "f" else "f32", ", ".join(re.findall(r"Li(\d+)E", m.group(3))), "cat" if m.group(4) == "1" else "plain")
+    m = re.search(r"_ZN2bf(?:12_GLOBAL__N_1)?(\d+)", name)
+    if name.startswith("_Z") and m:
+        i = name.index(m.group(1), m.start(1)) + len(m.group(1))
+        return name[i:i + int(m.group(1))] + "<f16 instantiation>"
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name[name.index("bf::") + 4:].split("(")[0] if "bf::" in name else name.split("(")[0]
 
 
 def _one(pattern):
