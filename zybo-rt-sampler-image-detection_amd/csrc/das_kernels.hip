@@ -1693,14 +1693,15 @@ __device__ __forceinline__ void pair_pad_rest(f32x2 (&acc)[8][2][2], Quad& S0, Q
 }
 
 // Profiling build only (-DBF_STAMPS, scripts/dev/phase_stamps.py): every wave sums the time it spends in each phase of
-// das_pair_kernel (s_memtime at the phase boundaries, which are barrier neighbours anyway) and adds the totals to
+// das_pair_kernel / das_pair2_kernel (s_memtime at the phase boundaries, which are barrier neighbours anyway) and adds the totals to
 // g_stamps[phase] when its workgroup ends.  BF_STAMP(k) closes the phase that was running and charges it to slot k:
 //   0 sweep  1 wait (chunk free)  2 staging  3 wait (chunk staged)  4 wait (power: rows free)  5 parking  6 wait (rows parked)  7 ordered sum
 #ifdef BF_STAMPS
-__device__ unsigned long long g_stamps[16];              // (sums over all waves; the flush is one atomic per wave and slot)
+__device__ unsigned long long g_stamps[64 * 16];         // (sums over all waves, in 64 replicas picked by workgroup id: nine atomics per wave on one
+                                                         //  line would make the flush longer than the kernel)
 #define BF_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_prev = __builtin_amdgcn_s_memtime();
 #define BF_STAMP(k) do { const unsigned long long st_now = __builtin_amdgcn_s_memtime(); st_acc[k] += st_now - st_prev; st_prev = st_now; } while (0)
-#define BF_STAMP_FLUSH do { if (lane == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[i], st_acc[i]); atomicAdd(&g_stamps[8], 1ull); } } while (0)
+#define BF_STAMP_FLUSH do { if (lane == 0) { unsigned long long* gs = g_stamps + 16 * (blockIdx.x & 63); for (int i = 0; i < 8; ++i) atomicAdd(&gs[i], st_acc[i]); atomicAdd(&gs[8], 1ull); } } while (0)
 #else
 #define BF_STAMP_DECL
 #define BF_STAMP(k)
@@ -2120,6 +2121,7 @@ __global__ void __launch_bounds__(1024, 4) das_pair2_kernel(BF_TABLE_PARAMS, KAr
         }
     };
 
+    BF_STAMP_DECL
     Staged2 st = fetch(0);
     const int lb = 16 * lane + (int)(unsigned)(size_t)((__attribute__((address_space(3))) char*)lds);
 
@@ -2130,10 +2132,14 @@ __global__ void __launch_bounds__(1024, 4) das_pair2_kernel(BF_TABLE_PARAMS, KAr
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[j][q] = f32x2{0.0f, 0.0f};
 
+        BF_STAMP(7);
         __syncthreads();   // the previous group's parked rows have been summed
+        BF_STAMP(1);
         stage(0, st, true);
         st = fetch(1 % n_half);
+        BF_STAMP(2);
         __syncthreads();
+        BF_STAMP(3);
 
         const int dw0 = g0 + wave * DW;                         // wave-uniform
         const bool busy = dw0 < tile_end;
@@ -2143,6 +2149,7 @@ __global__ void __launch_bounds__(1024, 4) das_pair2_kernel(BF_TABLE_PARAMS, KAr
                 stage(h + 1, st, h == 0);                       // into the half whose sweeps ended before the last barrier
                 if (h + 2 < n_half) st = fetch(h + 2);
                 else if (g0 + kGroup < tile_end) st = fetch(0);
+                BF_STAMP(2);
             }
             if (busy) {
                 const int32_t* __restrict__ et = dig + (grp * M + (size_t)h * HC) * DW;
@@ -2179,14 +2186,19 @@ __global__ void __launch_bounds__(1024, 4) das_pair2_kernel(BF_TABLE_PARAMS, KAr
                 mic(1, I1{});
                 __builtin_amdgcn_s_waitcnt(0xC07F);             // the entries requested past the half's end have landed (and are dropped)
             }
+            BF_STAMP(0);       // sweep -> waiting for the others
             __syncthreads();   // half h is free, half h + 1 is staged
+            BF_STAMP(h + 1 < n_half ? 3 : 4);
         }
 
         // ---- k-ordered mean power (pad_and_sum.c:120-128), one frame at a time: the 16 waves park the squared means of their
         // directions (row = direction, k in order; the rows alias the LDS image), then one direction per lane runs the sequential sum.
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            if (f == 1) __syncthreads();        // frame 0's rows have been summed
+            if (f == 1) {
+                __syncthreads();        // frame 0's rows have been summed
+                BF_STAMP(4);
+            }
             auto park = [&](auto mul_c) __attribute__((always_inline)) {
 #pragma unroll
                 for (int j = 0; j < DW; ++j) {
@@ -2206,7 +2218,9 @@ __global__ void __launch_bounds__(1024, 4) das_pair2_kernel(BF_TABLE_PARAMS, KAr
                 }
             };
             if (__builtin_expect(a.n_is_pow2, 1)) park(std::true_type{}); else park(std::false_type{});
+            BF_STAMP(5);                // -> waiting
             __syncthreads();
+            BF_STAMP(6);                // -> ordered sum (two waves; the others go on to the next barrier)
             int lane_o = lane;                            // (opaque: keeps the per-lane row address out of the registers the sweep needs)
             asm volatile("" : "+v"(lane_o));
             const int g = wave * kWave + lane_o;          // parked row of this lane
@@ -2228,6 +2242,8 @@ __global__ void __launch_bounds__(1024, 4) das_pair2_kernel(BF_TABLE_PARAMS, KAr
             }
         }
     }
+    BF_STAMP(7);
+    BF_STAMP_FLUSH;
 }
 
 // ==================================================================================================
@@ -3095,7 +3111,11 @@ static hipError_t refuse_scratch(K kernel, int* cached)
         if (e != hipSuccess) return e;
         *cached = (int)fa.localSizeBytes;
     }
+#ifdef BF_STAMPS
+    return hipSuccess;              // (the profiling build's stamp registers may spill: its phase shares are read, never its images)
+#else
     return *cached != 0 ? hipErrorInvalidDeviceFunction : hipSuccess;
+#endif
 }
 
 template <int ALGO, int NC>
@@ -3532,10 +3552,13 @@ long long digest_shareable_steps(const DasLaunch& L, const DasPlan& plan)
 hipError_t read_phase_stamps(unsigned long long* out16, bool clear)
 {
 #ifdef BF_STAMPS
-    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(copies::g_stamps), 16 * sizeof(unsigned long long));
-    if (e != hipSuccess || !clear) return e;
-    const unsigned long long zero[16] = {0};
-    return hipMemcpyToSymbol(HIP_SYMBOL(copies::g_stamps), zero, sizeof(zero));
+    static unsigned long long all[64 * 16];
+    hipError_t e = hipMemcpyFromSymbol(all, HIP_SYMBOL(copies::g_stamps), sizeof(all));
+    if (e != hipSuccess) return e;
+    for (int i = 0; i < 16; ++i) { out16[i] = 0; for (int r = 0; r < 64; ++r) out16[i] += all[16 * r + i]; }
+    if (!clear) return e;
+    for (int i = 0; i < 64 * 16; ++i) all[i] = 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(copies::g_stamps), all, sizeof(all));
 #else
     for (int i = 0; i < 16; ++i) out16[i] = 0;
     (void)clear;
