@@ -248,7 +248,7 @@ int bf_preprocess_bgr8_device(const void *d_frames, void *d_out, int batch, int 
 /*   bf_conv2d_nhwc_f16_device: the detector's convolutions (the network behind ultralytics.YOLO, yolo_smooth_tracking.py:9-23) as an
  *       implicit GEMM on the f16 matrix cores: y[b][ho][wo][n] = act(bias[n] + sum x[b][ho*stride-pad+i][wo*stride-pad+j][c] * w[n][i][j][c]),
  *       x float16 NHWC [batch][h][w][c]; w float16 [n][kh][kw][c], every output channel's kh*kw*c values followed by zeros up to a
- *       multiple of 32 (bf_conv2d_weight_row(kh, kw, c) halfs per row); bias float32 [n] or NULL; y float16 NHWC
+ *       multiple of 64 = whole 128-byte stages (bf_conv2d_weight_row(kh, kw, c) halfs per row); bias float32 [n] or NULL; y float16 NHWC
  *       [batch][(h+2*pad-kh)/stride+1][(w+2*pad-kw)/stride+1][n]; silu != 0 applies x*sigmoid(x) (f32 accumulation throughout).
  *       c a power of two >= 4 with kw * c a multiple of 8 (pad a 3-channel image with one zero channel; 4 channels need even
  *       stride, pad and width). */
@@ -268,7 +268,7 @@ int bf_conv2d_nhwc_f16_into_device(const void *d_x, const void *d_w, const float
 /*   float32 forms of the detector's tensor kernels -- the precision ultralytics' predict runs at by default
  *       (yolo_smooth_tracking.py:13-23 passes no half=): the same kernels on float32 NHWC tensors, the convolution on the exact-f32 matrix
  *       instruction v_mfma_f32_32x32x2_f32 (products and sums in f32, one rounding per product), SiLU as x / (1 + expf(-x)).
- *       Weight rows are padded to a multiple of 16 floats (bf_conv2d_weight_row_f32); c a power of two >= 4. */
+ *       Weight rows are padded to a multiple of 32 floats (bf_conv2d_weight_row_f32); c a power of two >= 4. */
 int bf_conv2d_weight_row_f32(int kh, int kw, int c);
 int bf_conv2d_nhwc_f32_device(const void *d_x, const void *d_w, const float *d_bias, void *d_y, int batch, int h, int w, int c, int n, int kh, int kw,
                               int stride, int pad, int silu, void *stream);

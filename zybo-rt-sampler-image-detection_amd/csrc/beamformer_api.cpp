@@ -1210,8 +1210,8 @@ int bf_preprocess_bgr8_f32_device(const void* d_frames, void* d_out, int batch, 
 
 int bf_conv2d_use_dma_kernel(int enable) { return bf::conv_dma_switch(enable); }
 
-int bf_conv2d_weight_row(int kh, int kw, int c) { return kh > 0 && kw > 0 && c > 0 ? (kh * kw * c + 31) / 32 * 32 : -1; }
-int bf_conv2d_weight_row_f32(int kh, int kw, int c) { return kh > 0 && kw > 0 && c > 0 ? (kh * kw * c + 15) / 16 * 16 : -1; }
+int bf_conv2d_weight_row(int kh, int kw, int c) { return kh > 0 && kw > 0 && c > 0 ? bf::conv_weight_row(2, kh, kw, c) : -1; }
+int bf_conv2d_weight_row_f32(int kh, int kw, int c) { return kh > 0 && kw > 0 && c > 0 ? bf::conv_weight_row(4, kh, kw, c) : -1; }
 
 static int conv2d_checked(const char* who, int eb, const void* d_x, const void* d_w, const float* d_bias, void* d_y, int batch, int h, int w, int c, int n, int kh,
                           int kw, int stride, int pad, int silu, int ldy, const void* d_res, int ldr, void* stream, bool cat = false, const void* d_x2 = nullptr,

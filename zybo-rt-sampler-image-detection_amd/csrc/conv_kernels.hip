@@ -59,6 +59,7 @@ struct ConvArgs {
     // between pixels; up1: x is [B][H/2][W/2] and read through a nearest-neighbour 2x upsampling), channels [c1, C) from x2 (ld2)
     const void* x2;
     int c1, ld1, ld2, up1;
+    int wld;              // elements between consecutive weight rows (rows are zero-padded to whole 128-byte stages)
 };
 
 // SiLU, x * sigmoid(x), of an f32 accumulator: exp by v_exp_f32 (2^(-x log2 e)), the reciprocal by v_rcp_f32 (1 ulp).  For a float32 layer one
@@ -127,7 +128,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const T* __restrict__ x
 #pragma unroll
     for (int i = 0; i < kBRows; ++i) {
         wv[i] = r + 64 * i < kBN && n0 + r + 64 * i < a.N;
-        wrow[i] = w + (size_t)(wv[i] ? n0 + r + 64 * i : 0) * n_stage * kBK;      // weight rows are padded to whole stages
+        wrow[i] = w + (size_t)(wv[i] ? n0 + r + 64 * i : 0) * a.wld;               // weight rows are padded to whole stages
     }
 
     vec ra[2], rb[kBRows];
@@ -275,59 +276,67 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const T* __restrict__ x
 typedef __attribute__((address_space(3))) void lds_void;
 constexpr unsigned kOob = 0x80000000u;
 
-template <typename T, int kBM_, int kBN> struct DmaGeo {
-    // ring depth: a float32 stage carries 32 MFMAs of 64 cycles per wave (one stage of loads in flight covers the memory latency, and the smaller
-    // ring admits a third workgroup per CU); a float16 stage is 8 MFMAs of 32 cycles, so two stages stay in flight
-    static constexpr int kDepth = sizeof(T) == 4 ? 3 : 4;
-    static constexpr int kStageBytes_ = (kBM_ + kBN) * 64;              // 64-byte rows
+template <typename T, int kBM_, int kBN, int kCPR> struct DmaGeo {
+    // kCPR: 16-byte chunks of K per row and stage -- 4 (64-byte rows) or 8 (128-byte rows: every row of a piece is one full cache line, half the
+    // barriers and address computations per byte; float16).
+    // Ring depth: a float32 stage carries 32 MFMAs of 64 cycles per wave (one stage of loads in flight covers the memory latency, and the smaller
+    // ring admits a third workgroup per CU); a float16 stage of 64-byte rows is 8 MFMAs of 32 cycles, so two stages stay in flight; 128-byte rows
+    // double the stage and run a ring of three where LDS allows two workgroups per CU with it, of two otherwise.
+    static constexpr int kRowBytes_ = 16 * kCPR;
+    static constexpr int kStageBytes_ = (kBM_ + kBN) * kRowBytes_;
+    static constexpr int kDepth = sizeof(T) == 4 ? 3 : (kCPR == 4 ? 4 : (3 * kStageBytes_ <= 80 * 1024 ? 3 : 2));
     static constexpr int kRingBytes = kDepth * kStageBytes_;
-    static constexpr int kAPieces = kBM_ / 64;                          // 1-KiB pieces (16 rows) of the pixel tile per wave and stage
-    static constexpr int kBPieces = kBN == 128 ? 2 : 1;                 // ... of the weight tile (kBN = 32: half a piece)
+    static constexpr int kPieceRows = 64 / kCPR;                        // a 1-KiB piece = kPieceRows rows; piece p of a tile belongs to wave p % 4
+    static constexpr bool kHalfB = kBN / kPieceRows < 4;                // (32 channels, 64-byte rows: two pieces, issued as four half pieces)
+    static constexpr int kAPieces = kBM_ / kPieceRows / 4;
+    static constexpr int kBPieces = kHalfB ? 1 : kBN / kPieceRows / 4;
     static constexpr int kPerStage = kAPieces + kBPieces;               // DMA instructions a wave issues per stage
     // the waves' grid over the tile, 32 x 32 MFMA tiles per wave
     static constexpr int kWN = kBN == 128 ? 2 : (kBM_ == 64 && kBN == 64 ? 2 : 1), kWM = 4 / kWN;
     static constexpr int kTM = kBM_ / kWM / 32, kTN = kBN / kWN / 32;
-    static_assert(kTM >= 1 && kTN >= 1, "every wave owns at least one MFMA tile");
+    static_assert(kTM >= 1 && kTN >= 1 && kAPieces >= 1, "every wave owns at least one MFMA tile and one piece");
     // the epilogue hands the tile to the stores one 32-column block per wave column at a time
     static constexpr int kCCols = kWN * 32;
+    // slot of logical chunk c in row r: spreads the 16 rows of a ds_read_b128 lane group over all 64 banks
+    __device__ static constexpr int swz(int r) { return kCPR == 4 ? (r >> 2) & 3 : (r >> 1) & 7; }
 };
 
 // (The body lives in a __device__ function: the buffer-descriptor type of the LDS-DMA builtins does not exist in the host pass, and a kernel whose
 //  body the host pass cannot parse gets no launch stub; a __device__ function's host-side diagnostics are deferred and dropped.)
-template <typename T, int kBM_, int kBN, bool kCat>
+template <typename T, int kBM_, int kBN, int kCPR, bool kCat>
 __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y, const ConvArgs& a,
                                               unsigned x_bytes, unsigned x2_bytes, unsigned w_bytes)
 {
     typedef typename Elem<T>::vec vec;
-    typedef DmaGeo<T, kBM_, kBN> G;
+    typedef DmaGeo<T, kBM_, kBN, kCPR> G;
     constexpr int E = Elem<T>::E;
     constexpr bool kF32 = sizeof(T) == 4;
     constexpr int kWM = G::kWM, kTM = G::kTM, kTN = G::kTN;
     constexpr int kCRow = G::kCCols + E;
     constexpr int kTileBytes = kBM_ * kCRow * (int)sizeof(T);
-    constexpr int D = G::kDepth;
+    constexpr int D = G::kDepth, RB = G::kRowBytes_, PR = G::kPieceRows;
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::kRingBytes > kTileBytes ? G::kRingBytes : kTileBytes];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % kWM, wn = wave / kWM;
     const long long m0 = (long long)blockIdx.x * kBM_;
     const int n0 = blockIdx.y * kBN;
-    const int cpk = (a.KW * a.C) / E, n_chunk = a.KH * cpk, n_stage = (n_chunk + 3) >> 2;
+    const int cpk = (a.KW * a.C) / E, n_chunk = a.KH * cpk, n_stage = (n_chunk + kCPR - 1) / kCPR;
 
     // buffer descriptors (wave-uniform): reads past num_records return zeros
     const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, (int)x_bytes, 0x00020000);
     const auto rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(kCat && a.x2 ? a.x2 : static_cast<const void*>(x)), 0, (int)(kCat && a.x2 ? x2_bytes : x_bytes), 0x00020000);
     const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(w), 0, (int)w_bytes, 0x00020000);
 
-    // ---- what this lane fills.  Pixel tile: piece j of wave `wave` = chunks (kAPieces wave + j) 64 + lane of the stage: row (..) 16 + lane / 4,
-    // slot lane % 4, i.e. the row's chunk ck = (lane & 3) ^ ((lane >> 4) & 3) (the same for every piece: their rows are multiples of 16 apart).
-    const int ck = (lane & 3) ^ ((lane >> 4) & 3);
+    // ---- what this lane fills.  Piece p = wave + 4 j of the pixel tile = its rows [p PR, (p + 1) PR): lane l fills row p PR + l / kCPR, slot l % kCPR,
+    // i.e. the row's logical chunk ck = slot ^ swz(row) -- the same for every piece of the wave (their rows differ by multiples of 4 PR).
+    const int ck = (lane % kCPR) ^ G::swz(wave * PR + lane / kCPR);
     unsigned abase[G::kAPieces];                            // byte offset of the row's pixel (kCat: in source 1 / source 2), or kOob
     unsigned abase2[G::kAPieces];
     int hi0[G::kAPieces], wi0[G::kAPieces];
 #pragma unroll
     for (int j = 0; j < G::kAPieces; ++j) {
-        const int row = (G::kAPieces * wave + j) * 16 + (lane >> 2);
+        const int row = (wave + 4 * j) * PR + lane / kCPR;
         const long long m = m0 + row;
         const bool pv = m < a.M;
         const unsigned mm = pv ? (unsigned)m : 0u;
@@ -349,16 +358,16 @@ __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* 
             abase[j] = b * (unsigned)(a.H * a.W * a.C) * (unsigned)sizeof(T);
         }
     }
-    // the chunk's position in K: kh and the chunk index inside the kh run, advanced by four chunks per stage
+    // the chunk's position in K: kh and the chunk index inside the kh run, advanced by kCPR chunks per stage
     int kh = ck / cpk, kk = ck - kh * cpk;
-    // Weight tile: piece j = chunks (kBPieces wave + j) 64 + lane: row (..) 16 + lane / 4 (kBN = 32: lanes 0..31 of a piece, rows wave 8 + lane / 4)
+    // Weight tile: the same pieces over its kBN rows (kHalfB: waves fill rows [8 wave, 8 wave + 8) with their lanes 0..31)
     unsigned wbase[G::kBPieces];
 #pragma unroll
     for (int j = 0; j < G::kBPieces; ++j) {
-        const int row = kBN == 32 ? wave * 8 + (lane >> 2) : (G::kBPieces * wave + j) * 16 + (lane >> 2);
+        const int row = G::kHalfB ? wave * 8 + (lane >> 2) : (wave + 4 * j) * PR + lane / kCPR;
         const int n = n0 + row;
-        const int ckb = (lane & 3) ^ ((row >> 2) & 3);      // (= ck except in the 32-channel tile, whose pieces are half as tall)
-        wbase[j] = n < a.N ? (unsigned)n * (unsigned)(n_stage * 64) + 16u * (unsigned)ckb : kOob;    // rows are padded to whole stages
+        const int ckb = (lane % kCPR) ^ G::swz(row);
+        wbase[j] = n < a.N ? ((unsigned)n * (unsigned)a.wld) * (unsigned)sizeof(T) + 16u * (unsigned)ckb : kOob;
     }
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
 
@@ -366,12 +375,12 @@ __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* 
         const unsigned slot = lds0 + (unsigned)(ring * G::kStageBytes_);
         const bool live = s < n_stage;
         if constexpr (kCat) {
-            const int c = (4 * s + ck) * E;                // chunk = channels [c, c + E) of the concatenation; a stage lies in one source (c1 % (4 E) == 0)
-            const bool second = 4 * s * E >= a.c1;
+            const int c = (kCPR * s + ck) * E;             // chunk = channels [c, c + E) of the concatenation; a stage lies in one source (c1 % (kCPR E) == 0)
+            const bool second = kCPR * s * E >= a.c1;
 #pragma unroll
             for (int j = 0; j < G::kAPieces; ++j) {
-                const unsigned off = (live && 4 * s + ck < n_chunk) ? (second ? abase2[j] : abase[j]) + (unsigned)c * (unsigned)sizeof(T) : kOob;
-                lds_void* dst = (lds_void*)(size_t)(slot + (unsigned)((G::kAPieces * wave + j) * 1024));
+                const unsigned off = (live && kCPR * s + ck < n_chunk) ? (second ? abase2[j] : abase[j]) + (unsigned)c * (unsigned)sizeof(T) : kOob;
+                lds_void* dst = (lds_void*)(size_t)(slot + (unsigned)((wave + 4 * j) * 1024));
                 if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, dst, 16, off, 0, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst, 16, off, 0, 0, 0);
             }
@@ -382,17 +391,17 @@ __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* 
                 const int hi = hi0[j] + kh, wi = wi0[j] + kw;
                 const bool ok = live && kh < a.KH && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
                 const unsigned off = ok ? abase[j] + (unsigned)((hi * a.W + wi) * a.C + c) * (unsigned)sizeof(T) : kOob;
-                lds_void* dst = (lds_void*)(size_t)(slot + (unsigned)((G::kAPieces * wave + j) * 1024));
+                lds_void* dst = (lds_void*)(size_t)(slot + (unsigned)((wave + 4 * j) * 1024));
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst, 16, off, 0, 0, 0);
             }
-            kk += 4;
+            kk += kCPR;
             while (kk >= cpk) { kk -= cpk; ++kh; }
         }
 #pragma unroll
         for (int j = 0; j < G::kBPieces; ++j) {
-            const unsigned off = live ? wbase[j] + (unsigned)(s * 64) : kOob;
-            lds_void* dst = (lds_void*)(size_t)(slot + (unsigned)(kBM_ * 64) + (unsigned)((kBN == 32 ? wave * 512 : (G::kBPieces * wave + j) * 1024)));
-            if (kBN != 32 || lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, dst, 16, off, 0, 0, 0);
+            const unsigned off = live ? wbase[j] + (unsigned)(s * RB) : kOob;
+            lds_void* dst = (lds_void*)(size_t)(slot + (unsigned)(kBM_ * RB) + (unsigned)(G::kHalfB ? wave * 512 : (wave + 4 * j) * 1024));
+            if (!G::kHalfB || lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, dst, 16, off, 0, 0, 0);
         }
     };
 
@@ -404,12 +413,12 @@ __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][t][e] = 0.0f;
 
-    // fragment reads: row (lane & 31) of a 32-row block, logical chunk (lane >> 5) + 2 k2 -> slot ^ ((row >> 2) & 3)
-    const int sw = (lane >> 2) & 3;
-    const unsigned fa = (unsigned)((wm * 32 * kTM + (lane & 31)) * 64), fb = (unsigned)(kBM_ * 64 + (wn * 32 * kTN + (lane & 31)) * 64);
-    unsigned fo[2];
+    // fragment reads: row (lane & 31) of a 32-row block, logical chunk (lane >> 5) + 2 k2 -> slot ^ swz(row)
+    const int sw = G::swz(lane & 31);
+    const unsigned fa = (unsigned)((wm * 32 * kTM + (lane & 31)) * RB), fb = (unsigned)(kBM_ * RB + (wn * 32 * kTN + (lane & 31)) * RB);
+    unsigned fo[kCPR / 2];
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) fo[k2] = (unsigned)((((lane >> 5) + 2 * k2) ^ sw) * 16);
+    for (int k2 = 0; k2 < kCPR / 2; ++k2) fo[k2] = (unsigned)((((lane >> 5) + 2 * k2) ^ sw) * 16);
 
 #pragma unroll
     for (int s = 0; s < D - 1; ++s) issue(s, s);
@@ -417,25 +426,19 @@ __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* 
     for (int s = 0; s < n_stage; ++s) {
         // this wave's pieces of stage s have landed once at most (D - 2) younger stages' are outstanding; the barrier extends that to every wave's
         // pieces, and says that every wave has finished reading stage s - 1, whose slot the next issue refills
-        constexpr int kInFlight = (D - 2) * G::kPerStage;
-        static_assert(kInFlight == 2 || kInFlight == 3 || kInFlight == 4 || kInFlight == 6 || kInFlight == 8, "a wait instruction per count");
-        if constexpr (kInFlight == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        if constexpr (kInFlight == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        if constexpr (kInFlight == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        if constexpr (kInFlight == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        if constexpr (kInFlight == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 2) * G::kPerStage) : "memory");
         __builtin_amdgcn_s_barrier();
         issue(s + D - 1, wr);
         const unsigned char* st = smem + rd * G::kStageBytes_;
         rd = rd + 1 == D ? 0 : rd + 1;
         wr = wr + 1 == D ? 0 : wr + 1;
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
+        for (int k2 = 0; k2 < kCPR / 2; ++k2) {
             vec af[kTM], bf[kTN];
 #pragma unroll
-            for (int i = 0; i < kTM; ++i) af[i] = *reinterpret_cast<const vec*>(st + fa + 32 * 64 * i + fo[k2]);
+            for (int i = 0; i < kTM; ++i) af[i] = *reinterpret_cast<const vec*>(st + fa + 32 * RB * i + fo[k2]);
 #pragma unroll
-            for (int t = 0; t < kTN; ++t) bf[t] = *reinterpret_cast<const vec*>(st + fb + 32 * 64 * t + fo[k2]);
+            for (int t = 0; t < kTN; ++t) bf[t] = *reinterpret_cast<const vec*>(st + fb + 32 * RB * t + fo[k2]);
             if constexpr (kF32) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -501,11 +504,11 @@ __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* 
     }
 }
 
-template <typename T, int kBM_, int kBN, bool kCat>
+template <typename T, int kBM_, int kBN, int kCPR, bool kCat>
 __global__ void __launch_bounds__(256) conv_dma_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y, ConvArgs a,
                                                        unsigned x_bytes, unsigned x2_bytes, unsigned w_bytes)
 {
-    conv_dma_body<T, kBM_, kBN, kCat>(x, w, bias, y, a, x_bytes, x2_bytes, w_bytes);
+    conv_dma_body<T, kBM_, kBN, kCPR, kCat>(x, w, bias, y, a, x_bytes, x2_bytes, w_bytes);
 }
 
 // Camera frames -> network input (yolo_smooth_tracking.py:9-23 hands ultralytics BGR uint8 frames; its letterbox-free part is
@@ -634,10 +637,21 @@ hipError_t launch_conv_t(const ConvArgs& a, const void* x, const void* w, const 
             if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cus = v; else n_cus = 256;
         }
         const DmaTile t = pick_dma_tile(a.M, a.N, n_cus, sizeof(T) == 4);
-#define BF_DMA_LAUNCH(BM, BN, CAT)                                                                                                                         \
-        hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, CAT>), dim3((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN)), dim3(256), 0, stream,  \
+        // Rows of 128 bytes (full cache lines per row, half the barriers per MFMA) pay where stages are many and the tile is 128 channels wide: float16
+        // layers of 128+ channels with K >= 1024, or 1x1 layers with K >= 512 (profiles/r03_conv_layers_f16.csv; the stem and the 32- / 64-channel layers
+        // lose to the coarser K padding and the smaller ring).  float32 stages are long as they are: 64-byte rows.  $BF_CONV_ROW=64|128 forces either.
+        static const int row_env = [] { const char* e = getenv("BF_CONV_ROW"); return e ? atoi(e) : 0; }();
+        const int K = a.KH * a.KW * a.C;
+        bool wide_rows = row_env == 128 ? true : (row_env == 64 ? false : (sizeof(T) == 2 && a.N >= 128 && (K >= 1024 || (a.KH == 1 && K >= 512))));
+        if (cat && a.x2 && (a.c1 % (8 * (16 / (int)sizeof(T)))) != 0) wide_rows = false;
+#define BF_DMA_LAUNCH(BM, BN, CPR, CAT)                                                                                                                          \
+        hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, CPR, CAT>), dim3((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN)), dim3(256), 0, stream,  \
                            xp, wp, bias, yp, a, x_bytes, x2_bytes, w_bytes)
-#define BF_DMA_PICK(BM, BN) do { if (cat) BF_DMA_LAUNCH(BM, BN, true); else BF_DMA_LAUNCH(BM, BN, false); } while (0)
+#define BF_DMA_PICK(BM, BN)                                                                                                    \
+        do {                                                                                                                   \
+            if (wide_rows) { if (cat) BF_DMA_LAUNCH(BM, BN, 8, true); else BF_DMA_LAUNCH(BM, BN, 8, false); }                  \
+            else { if (cat) BF_DMA_LAUNCH(BM, BN, 4, true); else BF_DMA_LAUNCH(BM, BN, 4, false); }                            \
+        } while (0)
         if (t.bm == 128 && t.bn == 128) BF_DMA_PICK(128, 128);
         else if (t.bm == 128 && t.bn == 64) BF_DMA_PICK(128, 64);
         else if (t.bm == 128) BF_DMA_PICK(128, 32);
@@ -692,6 +706,13 @@ hipError_t launch_preprocess_bgr8(const void* frames, void* out, long long pixel
     return hipGetLastError();
 }
 
+// Elements per packed weight row [KH][KW][C]: zero-padded to whole 128-byte stages (the longest stage any kernel here walks).
+int conv_weight_row(int elem_bytes, int kh, int kw, int c)
+{
+    const int per = 128 / elem_bytes;
+    return (kh * kw * c + per - 1) / per * per;
+}
+
 // Which convolution kernel launch_conv2d_nhwc picks: 1 = LDS-DMA staging where its conditions hold (the default; $BF_CONV_DMA=0 changes it),
 // 0 = the register-staged kernel always.  value < 0 only reads.  Returns the previous setting.
 int conv_dma_switch(int value)
@@ -741,8 +762,8 @@ hipError_t launch_conv2d_nhwc(int elem_bytes, const void* x, const void* w, cons
     const unsigned long long src1_pixels = cat && up1 ? (unsigned long long)B * (H / 2) * (W / 2) : (unsigned long long)B * H * W;
     const unsigned long long xb = cat ? ((src1_pixels - 1) * (unsigned long long)ld1 + (unsigned long long)a.c1) * eb : src1_pixels * (unsigned long long)C * eb;
     const unsigned long long x2b = (cat && x2) ? (((unsigned long long)B * H * W - 1) * (unsigned long long)ld2 + (unsigned long long)(C - a.c1)) * eb : 0ull;
-    const unsigned long long n_stage = ((unsigned long long)KH * ((unsigned long long)KW * C / E) + 3) / 4;
-    const unsigned long long wb = (unsigned long long)N * n_stage * 64ull;
+    a.wld = conv_weight_row(elem_bytes, KH, KW, C);
+    const unsigned long long wb = (unsigned long long)N * (unsigned long long)a.wld * eb;
     const bool dma = want_dma != 0 && xb < 0x7ffffff0ull && x2b < 0x7ffffff0ull && wb < 0x7ffffff0ull && (!(cat && x2) || (a.c1 % (4 * E)) == 0);
     return elem_bytes == 4 ? launch_conv_t<float>(a, x, w, bias, y, cat, dma, (unsigned)xb, (unsigned)x2b, (unsigned)wb, stream)
                            : launch_conv_t<_Float16>(a, x, w, bias, y, cat, dma, (unsigned)xb, (unsigned)x2b, (unsigned)wb, stream);
