@@ -17,6 +17,7 @@
 // MFMA lane map (A: lane l holds A[i = l & 31][k = l >> 5]; B: B[k = l >> 5][j = l & 31]) reads 128-byte rows.
 // A complex product is four real MFMAs; conj(B) is a sign flip of the loaded imaginary part.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 namespace bf {
@@ -501,6 +502,165 @@ __global__ void __launch_bounds__(256) cholesky_inverse_kernel(const float* __re
     }
 }
 
+// The same factorisation + inverse for M <= 64 with the matrix in REGISTERS (BASELINE config 3's 64-microphone array): cholesky_inverse_kernel
+// walks the trailing block through LDS read-modify-write chains (137 us for 94 bins of 64 x 64, a fifth of the MVDR map).  Here thread
+// (ti, tc) of a 16 x 16 grid owns the 4 x 4 elements (ti + 16 a, tc + 16 b) of A -- and later of L and of X = L^-1 -- as named registers; a step
+// broadcasts one column (and, for the inverse, one row) through a double-buffered LDS vector, one barrier per step, and every thread applies the
+// rank-1 update to its 16 elements:
+//   factorisation, step j:  A[i][c] -= (a_ij / d_j) conj(a_cj)   (j < c <= i; the column stays unscaled, as in the LDS kernel: the same arithmetic);
+//   L[i][j] = a_ij / sqrt(d_j);
+//   inverse (forward elimination of [L | I]), step j:  X[j][:] *= 1 / L[j][j];  X[i][:] -= L[i][j] X[j][:]  (i > j).
+// Elements past M behave as an identity block.  Output as cholesky_inverse_kernel: transposed planes out[c][i] = X[i][c], zeros above the diagonal.
+__global__ void __launch_bounds__(256) cholesky_inverse_reg_kernel(const float* __restrict__ rre, const float* __restrict__ rim, size_t in_stride, int ld_in, int M,
+                                                                   float loading, const float* __restrict__ load_abs, float* __restrict__ lire_t,
+                                                                   float* __restrict__ liim_t, size_t out_stride, int ld_out, int* __restrict__ status,
+                                                                   int status_base)
+{
+    __shared__ float colr[2][64], coli[2][64];          // the broadcast column (factorisation: raw a_ij; inverse: L[i][j])
+    __shared__ float rowr[2][64], rowi[2][64];          // inverse: the scaled row X[j][:]
+    __shared__ float s_red[4];
+    __shared__ float rdiag[64];                         // 1 / L[j][j]
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int ti = t & 15, tc = t >> 4;                 // rows fastest: 16 consecutive lanes hold 16 consecutive rows of a column
+    const float* Rr = rre + (size_t)b * in_stride;
+    const float* Ri = rim + (size_t)b * in_stride;
+    float ar[4][4], ai[4][4];
+    float tr = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = ti + 16 * a, j = tc + 16 * c;
+            const bool in = i < M && j < M;
+            ar[a][c] = in ? Rr[(size_t)i * ld_in + j] : (i == j ? 1.0f : 0.0f);
+            ai[a][c] = in ? Ri[(size_t)i * ld_in + j] : 0.0f;
+            if (in && i == j) tr += ar[a][c];
+        }
+    // diagonal loading: relative to the block's trace, or absolute per bin
+    for (int off = 32; off > 0; off >>= 1) tr += __shfl_xor(tr, off, 64);
+    if ((t & 63) == 0) s_red[t >> 6] = tr;
+    __syncthreads();
+    const float load = load_abs ? load_abs[b] : loading * ((s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (float)M);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (ti + 16 * a == tc + 16 * c && ti + 16 * a < M) { ar[a][c] += load; ai[a][c] = 0.0f; }
+
+    // ---- factorisation.  Register arrays are indexed by constants only: the steps run as four instances of a 16-column block body whose block
+    // number is a template constant (a select chain over the block gets folded back into a dynamically indexed array -- and into scratch).
+    if (tc == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { colr[0][ti + 16 * a] = ar[a][0]; coli[0][ti + 16 * a] = ai[a][0]; }
+    }
+    __syncthreads();
+    auto fact_block = [&](auto BLK) __attribute__((always_inline)) {
+        constexpr int blk = decltype(BLK)::value;
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = 16 * blk + jj, cur = j & 1;
+            if (j >= M) return;                             // (uniform)
+            const float d = colr[cur][j];
+            if (t == 0) { if (!(d > 0.0f)) status[b] = status_base + j + 1; rdiag[j] = 1.0f / sqrtf(fmaxf(d, 1e-30f)); }
+            const float invd = 1.0f / fmaxf(d, 1e-30f);
+            float sr[4], si[4], cr[4], ci[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { sr[a] = colr[cur][ti + 16 * a] * invd; si[a] = coli[cur][ti + 16 * a] * invd; cr[a] = colr[cur][tc + 16 * a]; ci[a] = coli[cur][tc + 16 * a]; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int i = ti + 16 * a, cc = tc + 16 * c;
+                    if (cc > j && cc <= i) {                // (i > j follows)
+                        ar[a][c] -= sr[a] * cr[c] + si[a] * ci[c];
+                        ai[a][c] -= si[a] * cr[c] - sr[a] * ci[c];
+                    }
+                }
+            // the owners of column j + 1 publish it (updated through step j) into the other buffer
+            const int jn = j + 1;
+            if (jn < M && tc == (jn & 15)) {
+                if (jj < 15) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) { colr[cur ^ 1][ti + 16 * a] = ar[a][blk]; coli[cur ^ 1][ti + 16 * a] = ai[a][blk]; }
+                } else if constexpr (blk < 3) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) { colr[cur ^ 1][ti + 16 * a] = ar[a][blk + 1]; coli[cur ^ 1][ti + 16 * a] = ai[a][blk + 1]; }
+                }
+            }
+            __syncthreads();
+        }
+    };
+    fact_block(std::integral_constant<int, 0>{}); fact_block(std::integral_constant<int, 1>{});
+    fact_block(std::integral_constant<int, 2>{}); fact_block(std::integral_constant<int, 3>{});
+    // L[i][c] = a_ic / sqrt(d_c) below the diagonal (the diagonal lives on as rdiag), zero above; X starts as the identity
+    float xr[4][4], xi[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = ti + 16 * a, cc = tc + 16 * c;
+            const float rd = cc < M ? rdiag[cc] : 1.0f;
+            ar[a][c] = i > cc ? ar[a][c] * rd : 0.0f;
+            ai[a][c] = i > cc ? ai[a][c] * rd : 0.0f;
+            xr[a][c] = i == cc ? 1.0f : 0.0f;
+            xi[a][c] = 0.0f;
+        }
+    // ---- inverse: step j scales row j of X by 1 / L[j][j] and eliminates column j of L from the rows below
+    auto publish = [&](int j, int buf, auto BLK) __attribute__((always_inline)) {      // column j of L (owners: tc == j % 16), scaled row j of X (owners: ti == j % 16)
+        constexpr int blk = decltype(BLK)::value;
+        if (tc == (j & 15)) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { colr[buf][ti + 16 * a] = ar[a][blk]; coli[buf][ti + 16 * a] = ai[a][blk]; }
+        }
+        if (ti == (j & 15)) {
+            const float rd = rdiag[j];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { rowr[buf][tc + 16 * c] = xr[blk][c] * rd; rowi[buf][tc + 16 * c] = xi[blk][c] * rd; }
+        }
+    };
+    publish(0, 0, std::integral_constant<int, 0>{});
+    __syncthreads();
+    auto inv_block = [&](auto BLK) __attribute__((always_inline)) {
+        constexpr int blk = decltype(BLK)::value;
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = 16 * blk + jj, cur = j & 1;
+            if (j >= M) return;
+            float lr[4], li[4], yr[4], yi[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { lr[a] = colr[cur][ti + 16 * a]; li[a] = coli[cur][ti + 16 * a]; yr[a] = rowr[cur][tc + 16 * a]; yi[a] = rowi[cur][tc + 16 * a]; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int i = ti + 16 * a, cc = tc + 16 * c;
+                    if (i == j) { xr[a][c] = yr[c]; xi[a][c] = yi[c]; }                 // the scaled row itself
+                    else if (i > j && cc <= j) {
+                        xr[a][c] -= lr[a] * yr[c] - li[a] * yi[c];
+                        xi[a][c] -= lr[a] * yi[c] + li[a] * yr[c];
+                    }
+                }
+            if (j + 1 < M) {
+                if (jj < 15) publish(j + 1, cur ^ 1, std::integral_constant<int, blk>{});
+                else if constexpr (blk < 3) publish(j + 1, cur ^ 1, std::integral_constant<int, blk + 1>{});
+            }
+            __syncthreads();
+        }
+    };
+    inv_block(std::integral_constant<int, 0>{}); inv_block(std::integral_constant<int, 1>{});
+    inv_block(std::integral_constant<int, 2>{}); inv_block(std::integral_constant<int, 3>{});
+    float* Or = lire_t + (size_t)b * out_stride;
+    float* Oi = liim_t + (size_t)b * out_stride;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = ti + 16 * a, cc = tc + 16 * c;
+            if (i < M && cc < M) {
+                Or[(size_t)cc * ld_out + i] = i < cc ? 0.0f : xr[a][c];
+                Oi[(size_t)cc * ld_out + i] = i <= cc ? 0.0f : xi[a][c];
+            }
+        }
+}
+
 // ---- pieces of the blocked factorisation for 128 < M <= 256 (launch_fd_cholesky_inverse) -------------------------------
 // load[b] = loading * tr(R_b) / M over the whole matrix
 __global__ void __launch_bounds__(64) diag_load_kernel(const float* __restrict__ rre, int M, float loading, float* __restrict__ load)
@@ -701,6 +861,11 @@ hipError_t run_strided(const StridedGemm& g, int batch, hipStream_t stream)
 hipError_t run_cholesky(const float* rre, const float* rim, size_t in_stride, int ld_in, int m, float loading, const float* load_abs, float* ore, float* oim,
                         size_t out_stride, int ld_out, int* d_status, int status_base, int n_bins, hipStream_t stream)
 {
+    if (m <= 64) {                                         // the register-resident form
+        hipLaunchKernelGGL(cholesky_inverse_reg_kernel, dim3((unsigned)n_bins), dim3(256), 0, stream, rre, rim, in_stride, ld_in, m, loading, load_abs, ore, oim,
+                           out_stride, ld_out, d_status, status_base);
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)2 * m * (m + 1) * sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cholesky_inverse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
