@@ -287,6 +287,11 @@ int bf_conv1x1_cat_nhwc_f16_device(const void *d_x1, int ld1, int c1, int up1, c
                                    int ldy, const void *d_res, int ldr, int batch, int h, int w, int c, int n, int silu, void *stream);
 int bf_conv1x1_cat_nhwc_f32_device(const void *d_x1, int ld1, int c1, int up1, const void *d_x2, int ld2, const void *d_w, const float *d_bias, void *d_y,
                                    int ldy, const void *d_res, int ldr, int batch, int h, int w, int c, int n, int silu, void *stream);
+/*   bf_letterbox_bgr8_device: what ultralytics' predict does to a frame before the network (yolo_smooth_tracking.py:13-23): d_frame uint8 [h][w][3]
+ *       resized with cv2.resize(INTER_LINEAR) semantics (8-bit fixed-point bilinear, half-pixel centres) to new_w x new_h and placed at (top, left) of
+ *       d_out uint8 [out_h][out_w][3], whose other pixels get the border value (114 in ultralytics).  new_h == h and new_w == w copies. */
+int bf_letterbox_bgr8_device(const unsigned char *d_frame, int h, int w, unsigned char *d_out, int out_h, int out_w, int new_h, int new_w, int top, int left,
+                             int value, void *stream);
 int bf_nms_device(const float *d_boxes, const float *d_scores, const int *d_cls, const int *d_counts, int batch, int k, float iou_thres, int max_det,
                   unsigned long long *d_mask, float *d_out, int *d_out_count, void *stream);
 

@@ -84,6 +84,25 @@ def test_gpu_reference_named_caller(native):
     for a, b in zip(got, ref):
         assert a[4] == b[4] and a[0] == b[0] and a[2] == b[2]
         assert a[1] == min(max(b[1] - 12, 0.0), 360.0) and a[3] == min(max(b[3] - 12, 0.0), 360.0)
+    # a 720 x 1280 frame: ultralytics scales the long side to 640 first (LetterBox, cv2.resize INTER_LINEAR) -- the same boxes as the resized picture
+    # handed over directly, scaled back by 2
+    import torch
+    import visual_np as V
+    big = np.random.default_rng(3).integers(0, 256, (720, 1280, 3), dtype=np.uint8)
+    assert Y.letterbox_geometry(720, 1280) == (360, 640, 12, 0, 384, 640, 0.5) and Y.letterbox_geometry(360, 640)[:6] == (360, 640, 12, 0, 384, 640)
+    assert Y.letterbox_geometry(320, 320)[:6] == (640, 640, 0, 0, 640, 640) and Y.letterbox_geometry(480, 640)[:6] == (480, 640, 0, 0, 480, 640)
+    canvas = torch.empty((384, 640, 3), dtype=torch.uint8, device="cuda")
+    d_big = torch.from_numpy(big).cuda()
+    assert native.lib.bf_letterbox_bgr8_device(d_big.data_ptr(), 720, 1280, canvas.data_ptr(), 384, 640, 360, 640, 12, 0, 114, None) == 0, native.check()
+    want = np.full((384, 640, 3), 114, dtype=np.uint8)
+    want[12:372] = V.resize_linear_u8(big, 640, 360)
+    assert np.array_equal(canvas.cpu().numpy(), want)
+    got_big = m.get_detections(big, conf_threshold=0.001)
+    ref_small = m.get_detections(want, conf_threshold=0.001)          # already 384 x 640: no letterbox inside
+    assert got_big and len(got_big) == len(ref_small)
+    for a, b in zip(got_big, ref_small):
+        assert a[4] == b[4] and abs(a[0] - 2 * b[0]) < 1e-3 and abs(a[2] - 2 * b[2]) < 1e-3
+        assert abs(a[1] - min(max(2 * (b[1] - 12), 0.0), 720.0)) < 1e-3 and abs(a[3] - min(max(2 * (b[3] - 12), 0.0), 720.0)) < 1e-3
     valid, cand = Y.split_detections([[0, 0, 1, 1, 0.7], [0, 0, 1, 1, 0.3], [0, 0, 1, 1, 0.05]])
     assert len(valid) == 1 and len(cand) == 1
     assert abs(Y.compute_iou([0, 0, 10, 10], [5, 5, 15, 15]) - 25 / 175) < 1e-12

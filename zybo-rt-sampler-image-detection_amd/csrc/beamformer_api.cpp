@@ -1055,6 +1055,19 @@ int bf_power_center_device(const float* d_power, int frames, float* d_centers, f
     return HIP_OK(bf::launch_power_center(d_power, frames, s.sz.res_x, s.sz.res_y, d_centers, d_workspace, reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
 }
 
+int bf_letterbox_bgr8_device(const unsigned char* d_frame, int h, int w, unsigned char* d_out, int out_h, int out_w, int new_h, int new_w, int top, int left, int value,
+                             void* stream)
+{
+    std::lock_guard<std::mutex> lock(S().mu);
+    if (!d_frame || !d_out || h < 1 || w < 1 || out_h < 1 || out_w < 1 || new_h < 1 || new_w < 1 || top < 0 || left < 0 || top + new_h > out_h || left + new_w > out_w ||
+        value < 0 || value > 255) {
+        set_error("bf_letterbox_bgr8_device: %d x %d -> %d x %d at (%d, %d) of %d x %d, border %d", h, w, new_h, new_w, top, left, out_h, out_w, value);
+        return -1;
+    }
+    if (!ensure_device()) return -1;
+    return HIP_OK(bf::launch_letterbox(d_frame, h, w, d_out, out_h, out_w, new_h, new_w, top, left, value, reinterpret_cast<hipStream_t>(stream))) ? 0 : -1;
+}
+
 // ---------------------------------------------------------------- frequency-domain beamformers
 
 #define FD_ENTER(cond, name)                                                     \

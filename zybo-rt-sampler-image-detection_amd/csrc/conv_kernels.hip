@@ -284,7 +284,13 @@ template <typename T, int kBM_, int kBN, int kCPR> struct DmaGeo {
     // double the stage and run a ring of three where LDS allows two workgroups per CU with it, of two otherwise.
     static constexpr int kRowBytes_ = 16 * kCPR;
     static constexpr int kStageBytes_ = (kBM_ + kBN) * kRowBytes_;
-    static constexpr int kDepth = sizeof(T) == 4 ? 3 : (kCPR == 4 ? 4 : (3 * kStageBytes_ <= 80 * 1024 ? 3 : 2));
+#ifndef BF_F32_DEPTH
+#define BF_F32_DEPTH 2
+#endif
+#ifndef BF_F16_DEPTH
+#define BF_F16_DEPTH 3
+#endif
+    static constexpr int kDepth = sizeof(T) == 4 ? BF_F32_DEPTH : (kCPR == 4 ? BF_F16_DEPTH : (3 * kStageBytes_ <= 80 * 1024 ? 3 : 2));
     static constexpr int kRingBytes = kDepth * kStageBytes_;
     static constexpr int kPieceRows = 64 / kCPR;                        // a 1-KiB piece = kPieceRows rows; piece p of a tile belongs to wave p % 4
     static constexpr bool kHalfB = kBN / kPieceRows < 4;                // (32 channels, 64-byte rows: two pieces, issued as four half pieces)
@@ -427,7 +433,9 @@ __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* 
         // this wave's pieces of stage s have landed once at most (D - 2) younger stages' are outstanding; the barrier extends that to every wave's
         // pieces, and says that every wave has finished reading stage s - 1, whose slot the next issue refills
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 2) * G::kPerStage) : "memory");
+#ifndef BF_DIAG_NO_BARRIER                                  // (timing experiment only: waves uncoupled, results wrong)
         __builtin_amdgcn_s_barrier();
+#endif
         issue(s + D - 1, wr);
         const unsigned char* st = smem + rd * G::kStageBytes_;
         rd = rd + 1 == D ? 0 : rd + 1;

@@ -100,6 +100,9 @@ hipError_t launch_colorize(const float* d_power, int frames, int res_x, int res_
 hipError_t launch_overlay(const unsigned char* d_small, int frames, int small_w, int small_h, int out_w, int out_h, unsigned char* d_prev,
                           const unsigned char* d_camera, unsigned char* d_out, float w_prev, float w_new, float w_cam, float w_heat,
                           hipStream_t stream);
+// uint8 BGR frame [sh][sw][3] -> [oh][ow][3]: cv2.resize(INTER_LINEAR) to new_w x new_h at (top, left), the rest = value (heatmap_kernels.hip)
+hipError_t launch_letterbox(const unsigned char* d_src, int sh, int sw, unsigned char* d_out, int oh, int ow, int new_h, int new_w, int top, int left, int value,
+                            hipStream_t stream);
 hipError_t launch_power_center(const float* d_power, int frames, int rows, int cols, float* d_centers, float* d_workspace, hipStream_t stream);
 
 // frequency-domain beamformers (freq_kernels.hip): steering phasors, DFT of the selected bins, and the MFMA complex GEMM

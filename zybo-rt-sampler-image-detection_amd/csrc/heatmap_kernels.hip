@@ -124,6 +124,43 @@ __global__ void __launch_bounds__(256) overlay_kernel(const unsigned char* __res
     for (int ch = 0; ch < 3; ++ch) prev[o3 + ch] = (unsigned char)pv[ch];
 }
 
+// The detector's letterbox (what ultralytics' predict does to a frame before the network, yolo_smooth_tracking.py:13-23): the frame resized with
+// cv2.resize(INTER_LINEAR) to new_w x new_h -- the same 8-bit fixed-point bilinear as above -- centred in an out_w x out_h canvas of the border value.
+// One thread per output pixel, 3 channels.
+__global__ void __launch_bounds__(256) letterbox_kernel(const unsigned char* __restrict__ src, int sh, int sw, unsigned char* __restrict__ out, int oh, int ow, int new_h,
+                                                        int new_w, int top, int left, int value)
+{
+    const int px = blockIdx.x * blockDim.x + threadIdx.x;
+    if (px >= ow * oh) return;
+    const int oy = px / ow, ox = px - oy * ow;
+    unsigned char* o = out + (size_t)px * 3;
+    const int y = oy - top, x = ox - left;
+    if (y < 0 || y >= new_h || x < 0 || x >= new_w) { o[0] = o[1] = o[2] = (unsigned char)value; return; }
+    if (new_h == sh && new_w == sw) {                          // (no resampling: cv2.resize is skipped for equal shapes)
+        const unsigned char* s = src + ((size_t)y * sw + x) * 3;
+        o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
+        return;
+    }
+    auto coord = [](int d, int ssz, int dsz, int& i0, int& i1, int& w0, int& w1) {
+        float f = (float)((d + 0.5) * ((double)ssz / dsz) - 0.5);
+        int i = (int)floorf(f);
+        f -= i;
+        if (i < 0) { i = 0; f = 0.f; }
+        if (i >= ssz - 1) { i = ssz - 1; f = 0.f; i1 = i; } else i1 = i + 1;
+        i0 = i;
+        w0 = (int)rintf((1.0f - f) * 2048.0f);
+        w1 = (int)rintf(f * 2048.0f);
+    };
+    int x0, x1, wx0, wx1, y0, y1, wy0, wy1;
+    coord(x, sw, new_w, x0, x1, wx0, wx1);
+    coord(y, sh, new_h, y0, y1, wy0, wy1);
+    for (int ch = 0; ch < 3; ++ch) {
+        const int a = src[((size_t)y0 * sw + x0) * 3 + ch], b = src[((size_t)y0 * sw + x1) * 3 + ch];
+        const int c = src[((size_t)y1 * sw + x0) * 3 + ch], d = src[((size_t)y1 * sw + x1) * 3 + ch];
+        o[ch] = (unsigned char)((((wy0 * ((a * wx0 + b * wx1) >> 4)) >> 16) + ((wy1 * ((c * wx0 + d * wx1) >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
 // find_power_center: one workgroup per frame.  image[x][y] float32 (rows = x).  Returns (center_x, center_y) in the
 // reference's naming: centroid over columns then rows of the smoothed map.
 __global__ void __launch_bounds__(256) power_center_kernel(const float* __restrict__ power, int rows, int cols, float* __restrict__ centers,
@@ -191,6 +228,14 @@ hipError_t launch_overlay(const unsigned char* d_small, int frames, int small_w,
     const int px = out_w * out_h;
     hipLaunchKernelGGL(overlay_kernel, dim3((px + 255) / 256), dim3(256), 0, stream, d_small, frames, small_w, small_h, out_w, out_h, d_prev,
                        d_camera, d_out, w_prev, w_new, w_cam, w_heat);
+    return hipGetLastError();
+}
+
+hipError_t launch_letterbox(const unsigned char* d_src, int sh, int sw, unsigned char* d_out, int oh, int ow, int new_h, int new_w, int top, int left, int value,
+                            hipStream_t stream)
+{
+    if (sh < 1 || sw < 1 || oh < 1 || ow < 1 || new_h < 1 || new_w < 1 || top < 0 || left < 0 || top + new_h > oh || left + new_w > ow) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(letterbox_kernel, dim3((unsigned)((oh * ow + 255) / 256)), dim3(256), 0, stream, d_src, sh, sw, d_out, oh, ow, new_h, new_w, top, left, value);
     return hipGetLastError();
 }
 

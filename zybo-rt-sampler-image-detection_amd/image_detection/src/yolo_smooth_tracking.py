@@ -111,6 +111,17 @@ class Detector:
         return self.postprocess(self.raw(self.preprocess(frames_u8)), conf_thres)
 
 
+def letterbox_geometry(h, w, imgsz=640, stride=32):
+    """ultralytics' LetterBox(imgsz, auto=True, scaleup=True, center=True) for an h x w frame -> (new_h, new_w, top, left, out_h, out_w, gain):
+    the long side is scaled to imgsz (up or down), the short side padded to the next multiple of the stride, the picture centred."""
+    r = min(imgsz / h, imgsz / w)
+    new_w, new_h = int(round(w * r)), int(round(h * r))
+    dw, dh = (imgsz - new_w) % stride, (imgsz - new_h) % stride
+    top, left = int(round(dh / 2 - 0.1)), int(round(dw / 2 - 0.1))
+    bottom, right = int(round(dh / 2 + 0.1)), int(round(dw / 2 + 0.1))
+    return new_h, new_w, top, left, new_h + top + bottom, new_w + left + right, r
+
+
 class yolo_model:
     """yolo_smooth_tracking.py:9-23"""
 
@@ -119,19 +130,19 @@ class yolo_model:
 
     def get_detections(self, frame, conf_threshold=0.0):
         """frame: uint8 [H, W, 3] BGR -> [[x1, y1, x2, y2, conf], ...] in the frame's pixel coordinates, conf >= conf_threshold.
-        A frame whose sides are not multiples of the network's largest stride (the reference's camera frames are 360 x 640,
-        main.pyx:632) is letterboxed the way ultralytics' predict does at scale 1: centred in the next multiple of 32 on a grey (114)
-        border, and the boxes are shifted back and clipped to the frame."""
+        The frame is letterboxed the way ultralytics' predict does it (long side scaled to 640 with cv2.resize(INTER_LINEAR) semantics, the
+        short side centred in the next multiple of 32 on a grey (114) border: the reference's 360 x 640 camera frames, main.pyx:632, run
+        at scale 1 in a 384 x 640 canvas); the boxes are shifted and scaled back and clipped to the frame (scale_boxes)."""
         t = self.model.torch
         frame = np.ascontiguousarray(frame)
         H, W = int(frame.shape[0]), int(frame.shape[1])
-        Hp, Wp = -(-H // 32) * 32, -(-W // 32) * 32
-        top, left = (Hp - H) // 2, (Wp - W) // 2
+        new_h, new_w, top, left, Hp, Wp, gain = letterbox_geometry(H, W)
         f = t.from_numpy(frame).to(self.model.device)
         if (Hp, Wp) != (H, W):
-            padded = t.full((Hp, Wp, 3), 114, dtype=t.uint8, device=self.model.device)
-            padded[top:top + H, left:left + W] = f
-            f = padded
+            canvas = t.empty((Hp, Wp, 3), dtype=t.uint8, device=self.model.device)
+            if nat.lib.bf_letterbox_bgr8_device(f.data_ptr(), H, W, canvas.data_ptr(), Hp, Wp, new_h, new_w, top, left, 114, t.cuda.current_stream().cuda_stream) != 0:
+                nat.check()
+            f = canvas
         out, n = self.model.detect(f.unsqueeze(0), conf_thres=max(1e-3, min(conf_threshold, 0.25)) if conf_threshold > 0 else 0.25)
         out, n = out[0].cpu().numpy(), int(n[0].item())
         dets = []
@@ -139,8 +150,8 @@ class yolo_model:
             if out[i, 4] < conf_threshold:
                 continue
             x1, y1, x2, y2 = (float(v) for v in out[i, :4])
-            x1, x2 = min(max(x1 - left, 0.0), float(W)), min(max(x2 - left, 0.0), float(W))
-            y1, y2 = min(max(y1 - top, 0.0), float(H)), min(max(y2 - top, 0.0), float(H))
+            x1, x2 = min(max((x1 - left) / gain, 0.0), float(W)), min(max((x2 - left) / gain, 0.0), float(W))
+            y1, y2 = min(max((y1 - top) / gain, 0.0), float(H)), min(max((y2 - top) / gain, 0.0), float(H))
             dets.append([x1, y1, x2, y2, float(out[i, 4])])
         return dets
 
