@@ -440,6 +440,9 @@ __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* 
         const unsigned char* st = smem + rd * G::kStageBytes_;
         rd = rd + 1 == D ? 0 : rd + 1;
         wr = wr + 1 == D ? 0 : wr + 1;
+#ifdef BF_CONV_PRIO
+        __builtin_amdgcn_s_setprio(BF_CONV_PRIO);
+#endif
 #pragma unroll
         for (int k2 = 0; k2 < kCPR / 2; ++k2) {
             vec af[kTM], bf[kTN];
@@ -461,6 +464,9 @@ __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* 
                     for (int t = 0; t < kTN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[t], acc[i][t], 0, 0, 0);
             }
         }
+#ifdef BF_CONV_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the tail's dummy pieces: the ring is reused by the output tile
 
