@@ -321,7 +321,8 @@ __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* 
     constexpr int kCRow = G::kCCols + E;
     constexpr int kTileBytes = kBM_ * kCRow * (int)sizeof(T);
     constexpr int D = G::kDepth, RB = G::kRowBytes_, PR = G::kPieceRows;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[G::kRingBytes > kTileBytes ? G::kRingBytes : kTileBytes];
+    constexpr int kMainBytes = G::kRingBytes > kTileBytes ? G::kRingBytes : kTileBytes;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kMainBytes + 512];      // ring / output image, then the tile's kBN bias values
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % kWM, wn = wave / kWM;
@@ -426,6 +427,15 @@ __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* 
 #pragma unroll
     for (int k2 = 0; k2 < kCPR / 2; ++k2) fo[k2] = (unsigned)((((lane >> 5) + 2 * k2) ^ sw) * 16);
 
+    // The tile's bias values travel like the operands: one LDS-DMA piece of 4-byte lanes (waves 0 and 1, 64 channels each; channels past the last are
+    // out of the descriptor's range: zeros), the oldest vector-memory operation of its wave, landed long before the epilogue reads it -- an ordinary
+    // global load there would sit on its latency with nothing left to overlap it (a short layer's whole K is one or two stages), and one here would
+    // make hipcc wait for it before the first DMA.
+    if (bias != nullptr && wave * 64 < kBN) {
+        const auto rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, a.N * 4, 0x00020000);
+        lds_void* dst = (lds_void*)(size_t)(lds0 + (unsigned)kMainBytes + (unsigned)(wave * 256));
+        if (kBN >= 64 || lane < kBN) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 4, (unsigned)(n0 + wave * 64 + lane) * 4u, 0, 0, 0);
+    }
 #pragma unroll
     for (int s = 0; s < D - 1; ++s) issue(s, s);
     int rd = 0, wr = D - 1;                                   // ring slots: stage s is read from rd, stage s + D - 1 goes to wr (= the slot stage s - 1 left)
@@ -480,8 +490,8 @@ __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* 
     for (int t = 0; t < kTN; ++t) {
         __syncthreads();                                       // the stage buffers (pass 0) / the previous pass's image have been read
         {
-            const int col = wn * 32 + (lane & 31), n = n0 + wn * 32 * kTN + 32 * t + (lane & 31);
-            const float bn = (bias && n < a.N) ? bias[n] : 0.0f;
+            const int col = wn * 32 + (lane & 31);
+            const float bn = bias != nullptr ? reinterpret_cast<const float*>(smem + kMainBytes)[wn * 32 * kTN + 32 * t + (lane & 31)] : 0.0f;
 #pragma unroll
             for (int i = 0; i < kTM; ++i) {
 #pragma unroll
@@ -492,9 +502,10 @@ __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* 
                 }
             }
         }
+        constexpr int kJ = (kBM_ * kCC + 255) / 256;
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < (kBM_ * kCC + 255) / 256; ++j) {
+        for (int j = 0; j < kJ; ++j) {
             const int id = tid + 256 * j, row = id / kCC, cq = id % kCC;
             const int wcol = (cq * E) / 32, cin = (cq * E) % 32;       // the wave column the chunk came from, its place in that wave's 32 columns
             const int nn = n0 + wcol * 32 * kTN + 32 * t + cin;         // first output channel of the chunk
