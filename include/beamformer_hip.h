@@ -205,7 +205,9 @@ int bf_power_center_device(const float *d_power, int frames, float *d_centers, f
  *   bf_fd_covariance_device R[k] = (1/F) sum_f x x^H                                                              -> [K][M][M]
  *   bf_fd_cholesky_inverse_device  R += loading*tr(R)/M*I = L L^H;  writes inverse(L) transposed [K][col][row];  M <= 256 (two blocks of 128 above 128);
  *                           d_status int32 [K] (zeroed by the caller) receives j+1 where a pivot was not positive
- *   bf_fd_mvdr_power_device P[d] = sum_k 1 / || inverse(L_k) a[k][:, d] ||^2                                     -> float32 [D]  */
+ *   bf_fd_mvdr_power_device P[d] = sum_k 1 / || inverse(L_k) a[k][:, d] ||^2                                     -> float32 [D]
+ *                           d_lire_t / d_liim_t are the planes bf_fd_cholesky_inverse_device writes, [K][col][row] of a LOWER-TRIANGULAR inverse: entries with
+ *                           col > row are taken to be zero and whole 32 x 32 blocks of them are not multiplied at all  */
 int bf_fd_steering_device(const double *d_tau, const double *d_freq, int n_dirs, int n_mics, int n_bins, float *d_are, float *d_aim, void *stream);
 int bf_fd_dft_device(const float *d_frames, int m_total, int frames, const int *adaptive_array, int n, int bin_lo, int n_bins,
                      float *d_xre_mf, float *d_xim_mf, float *d_xre_fm, float *d_xim_fm, void *stream);

@@ -275,6 +275,32 @@ def test_gpu_hip_convolution_f32_matches_fp64(native, B, C, H, W, N, k, s, p, si
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("half", [False, True])
+def test_gpu_hip_convolution_without_bias_and_with_a_ragged_channel_count(native, half):
+    """A convolution without a bias term (NULL pointer through the C-ABI) and 40 output channels (the 64-channel tile two thirds full, its bias piece
+    partly out of range): both kernels against torch."""
+    import torch
+    from image_detection.model import yolov5s
+    dt = torch.float16 if half else torch.float32
+    g = torch.Generator(device="cpu").manual_seed(17)
+    for bias in (False, True):
+        conv = torch.nn.Conv2d(64, 40, 3, 1, 1, bias=bias)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / 24.0)
+        conv = conv.cuda().to(dt)
+        x = torch.randn((2, 64, 18, 22), generator=g).cuda().to(dt).contiguous(memory_format=torch.channels_last)
+        hc = yolov5s.HipConv(conv, False)
+        got = hc(x)
+        native.lib.bf_conv2d_use_dma_kernel(0)
+        try:
+            assert torch.equal(got, hc(x))
+        finally:
+            native.lib.bf_conv2d_use_dma_kernel(1)
+        want = torch.nn.functional.conv2d(x.float(), conv.weight.float(), None if conv.bias is None else conv.bias.float(), 1, 1)
+        assert (got.float() - want).abs().max().item() / want.abs().max().item() < (2e-3 if half else 1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("half", [False, True])
 @pytest.mark.parametrize("up", [False, True])
 def test_gpu_hip_1x1_over_a_virtual_concatenation(native, half, up):
     """bf_conv1x1_cat_nhwc_*: a 1x1 layer reading torch.cat((upsample(a) if up else a, b), 1) from its two sources -- channel slices of

@@ -214,11 +214,12 @@ def test_gpu_bin_reducing_gemms_match_numpy(native, I, K, J, B):
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,J,B", [(37, 45, 9), (64, 333, 23), (100, 70, 4), (128, 200, 6)])
 def test_gpu_mvdr_quadratic_form_matches_numpy(native, M, J, B):
-    """bf_fd_mvdr_power_device on a random (transposed) triangular-inverse stand-in L[b, k, i]:
+    """bf_fd_mvdr_power_device on a random (transposed) triangular-inverse stand-in L[b, k, i] = Linv[i][k], zero for k > i as the planes of
+    bf_fd_cholesky_inverse_device are (the kernel does not multiply the all-zero 32 x 32 blocks):
     P[d] = sum_b 1 / sum_i |sum_k L[b,k,i] conj(A[b,k,d])|^2  against complex128 NumPy."""
     import torch
     rng = np.random.default_rng(M)
-    l = (rng.standard_normal((B, M, M)) + 1j * rng.standard_normal((B, M, M))).astype(np.complex64)
+    l = np.triu(rng.standard_normal((B, M, M)) + 1j * rng.standard_normal((B, M, M))).astype(np.complex64)
     a = np.exp(1j * rng.uniform(0, 2 * np.pi, (B, M, J))).astype(np.complex64)
     dev = lambda v: torch.from_numpy(np.ascontiguousarray(v)).cuda()
     lr, li, ar, ai = dev(l.real), dev(l.imag), dev(a.real), dev(a.imag)

@@ -210,17 +210,30 @@ __global__ void __launch_bounds__(256, 2) cgemm_bins_kernel(GemmArgs g, int row_
             f32x16 cre, cim;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { cre[r] = 0.0f; cim[r] = 0.0f; }
-            for (int k0 = 0; k0 < g.K; k0 += 64) {
+            // MVDR: the A operand is L^-1 (transposed planes), lower triangular -- rows [ib, ib + 32) meet columns k < ib + 32 only, so the k-steps
+            // beyond are products with zeros and are not issued (64 microphones: 192 instead of 256 MFMAs per bin and column tile).
+            const int kmax = (EPI == EPI_MVDR) ? min(g.K, ib + 32) : g.K;
+            for (int k0 = 0; k0 < kmax; k0 += 64) {
+                const bool both = k0 + 32 < kmax;              // (uniform) the panel's second half is needed
                 Panel Ap;
-                load_panel(Ap, are, aim, g.I, k0, g.K, lk, a_voff, a_ok, false);
+                load_panel(Ap, are, aim, g.I, k0, both ? g.K : min(g.K, k0 + 32), lk, a_voff, a_ok, false);
                 if (!single) load_panel(Bp, bre, bim, g.J, k0, g.K, lk, b_voff, bj_ok, g.conj_b != 0);
 #pragma unroll
-                for (int s2 = 0; s2 < 32; ++s2) {
+                for (int s2 = 0; s2 < 16; ++s2) {
                     // (xr + j xi)(yr + j yi)
                     cre = __builtin_amdgcn_mfma_f32_32x32x2f32(Ap.re[s2], Bp.re[s2], cre, 0, 0, 0);
                     cim = __builtin_amdgcn_mfma_f32_32x32x2f32(Ap.re[s2], Bp.im[s2], cim, 0, 0, 0);
                     cre = __builtin_amdgcn_mfma_f32_32x32x2f32(-Ap.im[s2], Bp.im[s2], cre, 0, 0, 0);
                     cim = __builtin_amdgcn_mfma_f32_32x32x2f32(Ap.im[s2], Bp.re[s2], cim, 0, 0, 0);
+                }
+                if (both) {
+#pragma unroll
+                    for (int s2 = 16; s2 < 32; ++s2) {
+                        cre = __builtin_amdgcn_mfma_f32_32x32x2f32(Ap.re[s2], Bp.re[s2], cre, 0, 0, 0);
+                        cim = __builtin_amdgcn_mfma_f32_32x32x2f32(Ap.re[s2], Bp.im[s2], cim, 0, 0, 0);
+                        cre = __builtin_amdgcn_mfma_f32_32x32x2f32(-Ap.im[s2], Bp.im[s2], cre, 0, 0, 0);
+                        cim = __builtin_amdgcn_mfma_f32_32x32x2f32(Ap.im[s2], Bp.re[s2], cim, 0, 0, 0);
+                    }
                 }
             }
             if constexpr (EPI == EPI_POWER) {
