@@ -165,7 +165,7 @@ def extras(torch, nat, delays, mics, dev):
         nat.lib.mimo_lerp(nat.fptr(one), nat.fptr(img1), nat.iptr(mics), M)
     dt = (time.perf_counter() - t0) / 300
     nat.check()
-    out["host_pointer_mimo_lerp"] = {"calls_per_s": 1.0 / dt, "us_per_call": dt * 1e6, "note": "one frame per call, host pointers, PCIe both ways, timed inside this process (torch loaded, other streams alive); "
+    out["host_pointer_mimo_lerp"] = {"calls_per_s": 1.0 / dt, "us_per_call": dt * 1e6, "note": "one frame per call, host pointers, PCIe both ways, timed inside this process (torch loaded, other streams alive; the call polls its stream before it blocks); "
                                                                                                     "scripts/host_path_latency.py measures the same call at 58 us standalone; real time needs 190.7 windows/s"}
     # config 4: float32 first -- the precision the reference's detector call runs at (ultralytics' predict default,
     # image-detection/src/yolo_smooth_tracking.py:13-23) -- then the float16 fast mode, labelled as such

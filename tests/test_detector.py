@@ -274,6 +274,31 @@ def test_gpu_hip_convolution_f32_matches_fp64(native, B, C, H, W, N, k, s, p, si
 
 
 @pytest.mark.gpu
+def test_gpu_convolution_past_the_dma_kernels_2_gib_range(native):
+    """The LDS-DMA kernel addresses its operands through 32-bit buffer offsets: an input tensor of 2 GiB or more (here float32 [136, 32, 352, 352] =
+    2.16 GB) must take the register-staged kernel by itself, and a tensor just under the limit the DMA kernel -- both against torch on the first and the
+    last image."""
+    import torch
+    from image_detection.model import yolov5s
+    g = torch.Generator(device="cpu").manual_seed(23)
+    conv = torch.nn.Conv2d(32, 64, 3, 2, 1, bias=True)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / 17.0)
+    conv = conv.cuda()
+    hc = yolov5s.HipConv(conv, True)
+    for B in (136, 132):                                # 2.16 GB and 2.09 GB: either side of 2^31 - 16 bytes
+        x = torch.empty((B, 32, 352, 352), dtype=torch.float32, device="cuda").contiguous(memory_format=torch.channels_last)
+        assert (x.numel() * 4 >= 2 ** 31) == (B == 136)
+        x.normal_(generator=None)
+        y = hc(x)
+        for b in (0, B - 1):
+            want = torch.nn.functional.silu(torch.nn.functional.conv2d(x[b:b + 1], conv.weight, conv.bias, 2, 1))
+            assert (y[b:b + 1] - want).abs().max().item() / want.abs().max().item() < 1e-5, (B, b)
+        del x, y
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("half", [False, True])
 def test_gpu_hip_convolution_without_bias_and_with_a_ragged_channel_count(native, half):
     """A convolution without a bias term (NULL pointer through the C-ABI) and 40 output channels (the 64-channel tile two thirds full, its bias piece

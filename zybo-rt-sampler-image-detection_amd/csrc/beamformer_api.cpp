@@ -5,6 +5,7 @@
 // file only validates, copies and enqueues.  There is no CPU compute path: when no GPU is usable every entry
 // point reports an error and poisons its output with NaN.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <algorithm>
 #include <cmath>
@@ -165,6 +166,20 @@ void poison(float* out, size_t n)
         if (e__ != hipSuccess) { set_error("%s -> %s", #expr, hipGetErrorString(e__)); return false; } \
         return true;                                                                          \
     }())
+
+// The host-pointer calls (one 64 KB frame in, one 40 KB map out) end in a wait for the stream.  hipStreamSynchronize may block or yield, depending on the
+// scheduling policy the runtime picks for the box (CPU count, other devices): the same call measured 58 us on one box and 206 us on another.  A call this
+// short is polled first -- hipStreamQuery in a spin for up to 2 ms -- and only then handed to the blocking wait.
+static hipError_t sync_short(hipStream_t stream)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    return hipStreamSynchronize(stream);
+}
 
 // ---- config.json reader: "KEY": number, anywhere in the file (keys are unique in PC/src/config.json)
 bool json_number(const std::string& text, const char* key, double* out)
@@ -411,7 +426,7 @@ void run_mimo_host(int algo, int slot, const float* signals, float* image, const
         ok = ok && ensure_digest(s.tab[slot], L, plan, s.stream);
         ok = ok && HIP_OK(bf::launch_das(L, plan, s.stream));
         ok = ok && HIP_OK(hipMemcpyAsync(s.h_image.p, s.d_image.p, D * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-        ok = ok && HIP_OK(hipStreamSynchronize(s.stream));
+        ok = ok && HIP_OK(sync_short(s.stream));
         if (ok) std::memcpy(image, s.h_image.p, D * sizeof(float));
     }
     if (!ok) poison(image, D);
@@ -456,7 +471,7 @@ void run_miso_host(int algo, const TableSet& t, const char* loader, bool fir, co
         ok = ok && plan_or_error(L, &plan);
         ok = ok && HIP_OK(bf::launch_miso(L, plan, row_offset, init ? s.d_init.p : nullptr, s.d_out.p, s.stream));
         ok = ok && HIP_OK(hipMemcpyAsync(out, s.d_out.p, N * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-        ok = ok && HIP_OK(hipStreamSynchronize(s.stream));
+        ok = ok && HIP_OK(sync_short(s.stream));
     }
     if (!ok) poison(out, N);
 }
@@ -495,7 +510,7 @@ void run_delay_host(int algo, const float* signal, float* out, bool accumulate, 
         ok = ok && plan_or_error(L, &plan);
         ok = ok && HIP_OK(bf::launch_miso(L, plan, 0, accumulate ? s.d_init.p : nullptr, s.d_out.p, s.stream));
         ok = ok && HIP_OK(hipMemcpyAsync(out, s.d_out.p, N * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-        ok = ok && HIP_OK(hipStreamSynchronize(s.stream));
+        ok = ok && HIP_OK(sync_short(s.stream));
     }
     if (!ok) poison(out, N);
 }
@@ -1014,7 +1029,7 @@ int bf_ingest(const void* packets, int n_arrays, int rows, int columns, float* f
     ok = ok && HIP_OK(hipMemcpyAsync(d_in.p, packets, in_bytes, hipMemcpyHostToDevice, s.stream));
     ok = ok && ingest_common(d_in.p, n_arrays, rows, columns, s.d_frame.p, s.stream) == 0;
     ok = ok && HIP_OK(hipMemcpyAsync(frame, s.d_frame.p, out_n * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-    ok = ok && HIP_OK(hipStreamSynchronize(s.stream));
+    ok = ok && HIP_OK(sync_short(s.stream));
     if (!ok) poison(frame, out_n);
     return ok ? 0 : -1;
 }
