@@ -256,7 +256,7 @@ int bf_preprocess_bgr8_device(const void *d_frames, void *d_out, int batch, int 
  *       stride, pad and width). */
 int bf_conv2d_weight_row(int kh, int kw, int c);
 /*   bf_conv2d_use_dma_kernel: the convolution entry points have two kernels behind them -- operand tiles staged by LDS-DMA (the default wherever
- *       every operand tensor is smaller than 2 GiB) or through registers.  enable = 1 / 0 selects, < 0 only asks; returns the previous setting
+ *       every operand tensor is smaller than 2 GiB) or through registers.  enable = 1 / 0 selects (2: as 1, and the stem's patch kernel in either precision), < 0 only asks; returns the previous setting
  *       ($BF_CONV_DMA=0 sets the initial one).  Results of the two are bit-identical (same products, same summation order). */
 int bf_conv2d_use_dma_kernel(int enable);
 int bf_conv2d_nhwc_f16_device(const void *d_x, const void *d_w, const float *d_bias, void *d_y, int batch, int h, int w, int c, int n, int kh, int kw,

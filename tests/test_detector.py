@@ -195,7 +195,9 @@ def test_gpu_topk_candidates_match_numpy(native, B, T, K):
 # ---- the detector's convolutions as this library's implicit-GEMM kernel (csrc/conv_kernels.hip)
 
 CONV_CASES = [  # (B, Cin, H, W, Cout, k, stride, pad, silu)      the layer shapes of yolov5s.py plus ragged tiles
-    (2, 3, 64, 96, 32, 6, 2, 2, True),        # the stem: 3 channels padded to 4, 6x6 window, stride 2
+    (2, 3, 64, 96, 32, 6, 2, 2, True),        # the stem: 3 channels padded to 4, 6x6 window, stride 2 (the patch kernel)
+    (1, 3, 70, 100, 32, 6, 2, 2, True),       # the stem on a picture whose 35 x 50 outputs leave ragged 8 x 16 pixel blocks
+    (2, 3, 40, 48, 24, 6, 2, 2, False),       # ... with 24 output channels (weight rows past the last channel), no activation
     (2, 32, 40, 40, 64, 3, 2, 1, True),       # a strided 3x3
     (1, 64, 20, 28, 64, 3, 1, 1, True),       # a bottleneck 3x3
     (3, 128, 17, 13, 64, 1, 1, 0, True),      # 1x1; 663 pixels: a ragged last pixel tile
@@ -262,6 +264,12 @@ def test_gpu_hip_convolution_f32_matches_fp64(native, B, C, H, W, N, k, s, p, si
         assert torch.equal(got, hc(xg))                # the register-staged kernel: the same products in the same order
     finally:
         native.lib.bf_conv2d_use_dma_kernel(1)
+    if C == 3:                                         # the stem's patch kernel is the default in float16 only: the same bits from it in float32
+        assert native.lib.bf_conv2d_use_dma_kernel(2) == 1
+        try:
+            assert torch.equal(got, hc(xg))
+        finally:
+            native.lib.bf_conv2d_use_dma_kernel(1)
     want32 = torch.nn.functional.conv2d(xg, conv.weight, conv.bias, s, p)
     if silu:
         want32 = torch.nn.functional.silu(want32)

@@ -536,6 +536,138 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(const T* __restrict__ x, 
     conv_dma_body<T, kBM_, kBN, kCPR, kCat>(x, w, bias, y, a, x_bytes, x2_bytes, w_bytes);
 }
 
+// ---- The stem (the network's first layer: 6x6 window, stride 2, 4 input channels after padding, 32 output channels) as a PATCH kernel.
+//
+// As an implicit GEMM the stem is the worst layer of the network (0.45 / 0.37 of its roofline in float32 / float16): its K walks 36 window pixels of 16
+// (8) bytes each, so every 1-KiB DMA piece is 64 separate little requests, each input pixel is fetched nine times, and the address arithmetic per MFMA is
+// the largest of any layer.  Here a workgroup owns an 8 x 16 block of output pixels of one image, loads the input PATCH under it once -- (7 s + KH) x
+// (15 s + KW) pixels, whole rows of contiguous bytes -- and all 32 weight rows once, by LDS-DMA, and then builds the A fragments of the same MFMAs straight
+// from the patch: the window pixel (kh, kw) of output pixel (ty, tx) is patch pixel (ty s + kh, tx s + kw).  K order, weight packing, the pairing of k
+// slots with lane halves and the epilogue are those of conv_dma_kernel, so the results are bit-identical to it.
+// Preconditions (launch_conv2d_nhwc checks them): C == 4, N <= 32, KW even, an even number of 16-byte chunks per window, patch + weights within LDS.
+struct PatchGeo {
+    static constexpr int kTH = 8, kTW = 16;                 // output pixels per tile
+};
+
+template <typename T>
+__device__ __forceinline__ void conv_patch_body(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y, const ConvArgs& a,
+                                                unsigned x_bytes, unsigned w_bytes)
+{
+    typedef typename Elem<T>::vec vec;
+    constexpr int E = Elem<T>::E;
+    constexpr bool kF32 = sizeof(T) == 4;
+    constexpr int kPix = 4 * (int)sizeof(T);                // bytes per (4-channel) pixel
+    constexpr int kCRow = 32 + E;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int PH = (PatchGeo::kTH - 1) * a.stride + a.KH, PW = (PatchGeo::kTW - 1) * a.stride + a.KW;
+    const int patch_bytes = (PH * PW * kPix + 1023) & ~1023;                    // whole pieces
+    const int wrow = a.wld * (int)sizeof(T), wstride = wrow + 16;               // LDS row pitch of the weights: 36 dwords past a multiple of 64 -> conflict-free reads
+    const int w_lds = 32 * wstride;
+    const int tiles_x = (a.Wo + PatchGeo::kTW - 1) / PatchGeo::kTW, tiles_y = (a.Ho + PatchGeo::kTH - 1) / PatchGeo::kTH;
+    const int b = blockIdx.x / (tiles_x * tiles_y), trem = blockIdx.x - b * (tiles_x * tiles_y);
+    const int oy0 = (trem / tiles_x) * PatchGeo::kTH, ox0 = (trem % tiles_x) * PatchGeo::kTW;
+    const int iy0 = oy0 * a.stride - a.pad, ix0 = ox0 * a.stride - a.pad;
+
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, (int)x_bytes, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(w), 0, (int)w_bytes, 0x00020000);
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+    const unsigned img = (unsigned)b * (unsigned)(a.H * a.W) * (unsigned)kPix;
+
+    // the patch: 16-byte chunk g of the patch image (float32: pixel g; float16: pixels 2 g, 2 g + 1 -- PW, ix0 and W are even there)
+    constexpr int kPPC = 16 / kPix;                          // pixels per chunk
+    const int chunks = PH * PW / kPPC, cpr = PW / kPPC;      // chunks in the patch, per patch row
+    for (int p = wave; p * 64 < chunks; p += 4) {
+        const int g = p * 64 + lane;
+        const int py = g / cpr, px = (g - py * cpr) * kPPC;
+        const int iy = iy0 + py, ix = ix0 + px;
+        const bool ok = g < chunks && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const unsigned off = ok ? img + (unsigned)(iy * a.W + ix) * (unsigned)kPix : kOob;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(size_t)(lds0 + (unsigned)(p * 1024)), 16, off, 0, 0, 0);
+    }
+    // the weights: LDS position -> (row, byte in the padded row); the pad and rows past the last channel are out-of-range lanes
+    for (int p = wave; p * 1024 < w_lds; p += 4) {
+        const int g = p * 1024 + lane * 16;
+        const int row = g / wstride, col = g - row * wstride;
+        const unsigned off = (g < w_lds && col < wrow && row < a.N) ? (unsigned)(row * wrow + col) : kOob;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(size_t)(lds0 + (unsigned)patch_bytes + (unsigned)(p * 1024)), 16, off, 0, 0, 0);
+    }
+    const int bias_at = patch_bytes + ((w_lds + 1023) & ~1023);
+    if (bias != nullptr && wave == 0) {
+        const auto rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, a.N * 4, 0x00020000);
+        if (lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(size_t)(lds0 + (unsigned)bias_at), 4, (unsigned)lane * 4u, 0, 0, 0);
+    }
+
+    // this lane's fragment rows: output pixel (ty, tx) of the tile (a wave owns two tile rows = 32 pixels), weight row lane & 31
+    const int r = lane & 31, half = lane >> 5;
+    const int ty = wave * 2 + (r >> 4), tx = r & 15;
+    const unsigned abase = (unsigned)((ty * a.stride) * PW + tx * a.stride) * (unsigned)kPix;
+    const unsigned bbase = (unsigned)patch_bytes + (unsigned)(r * wstride);
+    // chunk c of K = (kh, the c % cpk-th chunk of the kh run): lanes 0..31 take chunks 0, 2, .., lanes 32..63 chunks 1, 3, ..
+    const int cpk = (a.KW * 4) / E, n_chunk = a.KH * cpk;
+    int kh = half / cpk, kk = half - kh * cpk;
+    float16v acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = half; c < n_chunk; c += 2) {
+        const vec af = *reinterpret_cast<const vec*>(smem + abase + (unsigned)((kh * PW + kk * kPPC) * kPix));
+        const vec bf = *reinterpret_cast<const vec*>(smem + bbase + (unsigned)(c * 16));
+        if constexpr (kF32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc, 0, 0, 0);
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+        }
+        kk += 2;
+        while (kk >= cpk) { kk -= cpk; ++kh; }
+    }
+
+    // epilogue: bias, SiLU, transposed through LDS (the patch is done with), 16-byte stores of a pixel's 32 channels
+    const float bn = bias != nullptr ? reinterpret_cast<const float*>(smem + bias_at)[r] : 0.0f;
+    __syncthreads();
+    T* Cs = reinterpret_cast<T*>(smem);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        float v = acc[e] + bn;
+        if (a.act) v = silu_f(v, kF32);
+        Cs[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * kCRow + r] = (T)v;
+    }
+    __syncthreads();
+    constexpr int kCC = 32 / E;
+    const bool wide = a.wide != 0;
+    const T* res = static_cast<const T*>(a.res);
+#pragma unroll
+    for (int j = 0; j < (128 * kCC) / 256; ++j) {
+        const int id = tid + 256 * j, row = id / kCC, cc = (id % kCC) * E;
+        const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+        if (oy >= a.Ho || ox >= a.Wo || cc >= a.N) continue;
+        const size_t m = ((size_t)b * a.Ho + oy) * a.Wo + ox;
+        const T* src = &Cs[row * kCRow + cc];
+        T* dst = y + m * a.ldy + cc;
+        if (wide) {
+            vec v = *reinterpret_cast<const vec*>(src);
+            if (res) {
+                const vec rv = *reinterpret_cast<const vec*>(res + m * a.ldr + cc);
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[e] = (T)((float)v[e] + (float)rv[e]);
+            }
+            *reinterpret_cast<vec*>(dst) = v;
+        } else {
+            for (int e = 0; e < E && cc + e < a.N; ++e) dst[e] = res ? (T)((float)src[e] + (float)res[m * a.ldr + cc + e]) : src[e];
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) conv_patch_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y, ConvArgs a,
+                                                         unsigned x_bytes, unsigned w_bytes)
+{
+    conv_patch_body<T>(x, w, bias, y, a, x_bytes, w_bytes);
+}
+
 // Camera frames -> network input (yolo_smooth_tracking.py:9-23 hands ultralytics BGR uint8 frames; its letterbox-free part is
 // BGR -> RGB, / 255): [B][H][W][3] uint8 BGR -> [B][H][W][cpad] RGB in [0, 1] (float16 or float32), channels 3.. zero -- the NHWC
 // buffer the stem convolution reads.  (float)u * (1.0f / 255.0f), for float16 rounded once more: bit for bit what torch computes for u.half() / 255 and
@@ -661,6 +793,25 @@ hipError_t launch_conv_t(const ConvArgs& a, const void* x, const void* w, const 
             int dev = 0, v = 0;
             if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n_cus = v; else n_cus = 256;
         }
+        // the stem's shape: a 4-channel input under a wide window -- the patch kernel, in float16 (0.27 -> 0.19 ms at batch 64; in float32 both kernels sit
+        // on the 72 MFMAs per wave of the 4-channel K and the patch form measured 5 % slower: 0.68 against 0.64 ms).  $BF_CONV_PATCH=0 / 1: never / always (A/B).
+        static const int patch_env = [] { const char* e = getenv("BF_CONV_PATCH"); return e ? atoi(e) : -1; }();
+        const bool patch_wanted = conv_dma_switch(-1) == 2 ? true : (patch_env < 0 ? sizeof(T) == 2 : patch_env != 0);
+        if (patch_wanted && !cat && a.C == 4 && a.N <= 32 && a.KH * a.KW >= 16 && (a.KW & 1) == 0 && ((a.KH * a.KW * 4 / (16 / (int)sizeof(T))) & 1) == 0 &&
+            (sizeof(T) == 4 || ((a.stride & 1) == 0 && (a.pad & 1) == 0 && (a.W & 1) == 0))) {
+            const int PH = 7 * a.stride + a.KH, PW = 15 * a.stride + a.KW;
+            const int patch_bytes = (PH * PW * 4 * (int)sizeof(T) + 1023) & ~1023, w_lds = 32 * (a.wld * (int)sizeof(T) + 16);
+            const int lds = patch_bytes + ((w_lds + 1023) & ~1023) + 256, tile = 128 * (32 + 16 / (int)sizeof(T)) * (int)sizeof(T);
+            const int need = lds > tile ? lds : tile;
+            if (need <= 64 * 1024) {
+                auto kernel = conv_patch_kernel<T>;
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, need);
+                if (e != hipSuccess) return e;
+                const unsigned grid = (unsigned)a.B * (unsigned)((a.Ho + 7) / 8) * (unsigned)((a.Wo + 15) / 16);
+                hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), (size_t)need, stream, xp, wp, bias, yp, a, x_bytes, w_bytes);
+                return hipGetLastError();
+            }
+        }
         const DmaTile t = pick_dma_tile(a.M, a.N, n_cus, sizeof(T) == 4);
         // Rows of 128 bytes (full cache lines per row, half the barriers per MFMA) pay where stages are many and the tile is 128 channels wide: float16
         // layers of 128+ channels with K >= 1024, or 1x1 layers with K >= 512 (profiles/r03_conv_layers_f16.csv; the stem and the 32- / 64-channel layers
@@ -744,7 +895,7 @@ int conv_dma_switch(int value)
 {
     static int state = [] { const char* e = getenv("BF_CONV_DMA"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }();
     const int old = state;
-    if (value >= 0) state = value != 0 ? 1 : 0;
+    if (value >= 0) state = value > 2 ? 1 : value;         // 2: LDS-DMA kernels, and the patch kernel for every layer it can take (tests)
     return old;
 }
 
