@@ -48,6 +48,20 @@ constexpr int kBM = 128, kStageBytes = 64, kRowBytes = kStageBytes + 16;   // a 
 //   form a 2 x 2 grid of 64-pixel x 64-channel tiles (two A and two B fragments feed four MFMAs: one LDS read per MFMA instead of 1.5,
 //   a third less staging per MFMA), otherwise they stack 4 x 1 with 32-pixel x kBN tiles.
 
+// n / d for n < 2^31 and a divisor fixed at launch: q = (mulhi(magic, n) + n) >> shift (Granlund / Montgomery round-up form; the sum cannot overflow
+// below 2^31) -- three instructions where hipcc's unsigned division is about thirty.  The host fills it (make_fastdiv).
+struct FastDiv { unsigned magic, shift; };
+__device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv d) { return (__umulhi(d.magic, n) + n) >> d.shift; }
+inline FastDiv make_fastdiv(unsigned d)
+{
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    FastDiv f;
+    f.magic = (unsigned)((((1ull << l) - d) << 32) / d + 1ull);
+    f.shift = l;
+    return f;
+}
+
 struct ConvArgs {
     int B, H, W, C, Ho, Wo, N, KH, KW, stride, pad, act;
     int ldy, ldr;         // elements between consecutive pixels of the output / the residual
@@ -60,6 +74,8 @@ struct ConvArgs {
     const void* x2;
     int c1, ld1, ld2, up1;
     int wld;              // elements between consecutive weight rows (rows are zero-padded to whole 128-byte stages)
+    FastDiv d_img, d_row; // by Ho * Wo (pixel -> image) and by Wo (-> row)
+    FastDiv d_p0, d_p1, d_p2, d_p3;   // the patch kernel's: tiles per image, tiles per tile row, chunks per patch row, bytes per padded weight row
 };
 
 // SiLU, x * sigmoid(x), of an f32 accumulator: exp by v_exp_f32 (2^(-x log2 e)), the reciprocal by v_rcp_f32 (1 ulp).  For a float32 layer one
@@ -109,15 +125,15 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const T* __restrict__ x
         if constexpr (kCat) {
             px2[i] = static_cast<const T*>(a.x2) + (size_t)mm * a.ld2 - a.c1;          // indexed by the channel of the concatenation
             if (a.up1) {
-                const unsigned b = mm / (unsigned)(a.Wo * a.Ho), rem = mm - b * (unsigned)(a.Wo * a.Ho);
-                const unsigned ho = rem / (unsigned)a.Wo, wo = rem - ho * (unsigned)a.Wo;
+                const unsigned b = fdiv(mm, a.d_img), rem = mm - b * (unsigned)(a.Wo * a.Ho);
+                const unsigned ho = fdiv(rem, a.d_row), wo = rem - ho * (unsigned)a.Wo;
                 px[i] = x + ((size_t)(b * (unsigned)(a.Ho >> 1) + (ho >> 1)) * (unsigned)(a.Wo >> 1) + (wo >> 1)) * a.ld1;
             } else {
                 px[i] = x + (size_t)mm * a.ld1;
             }
         } else {
-            const unsigned b = mm / (unsigned)(a.Wo * a.Ho), rem = mm - b * (unsigned)(a.Wo * a.Ho);
-            const unsigned ho = rem / (unsigned)a.Wo, wo = rem - ho * (unsigned)a.Wo;
+            const unsigned b = fdiv(mm, a.d_img), rem = mm - b * (unsigned)(a.Wo * a.Ho);
+            const unsigned ho = fdiv(rem, a.d_row), wo = rem - ho * (unsigned)a.Wo;
             hi0[i] = (int)ho * a.stride - a.pad;
             wi0[i] = (int)wo * a.stride - a.pad;
             px[i] = x + (size_t)b * a.H * a.W * a.C;
@@ -351,15 +367,15 @@ __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* 
         if constexpr (kCat) {
             unsigned p1 = mm;
             if (a.up1) {
-                const unsigned b = mm / (unsigned)(a.Wo * a.Ho), rem = mm - b * (unsigned)(a.Wo * a.Ho);
-                const unsigned ho = rem / (unsigned)a.Wo, wo = rem - ho * (unsigned)a.Wo;
+                const unsigned b = fdiv(mm, a.d_img), rem = mm - b * (unsigned)(a.Wo * a.Ho);
+                const unsigned ho = fdiv(rem, a.d_row), wo = rem - ho * (unsigned)a.Wo;
                 p1 = (b * (unsigned)(a.Ho >> 1) + (ho >> 1)) * (unsigned)(a.Wo >> 1) + (wo >> 1);
             }
             abase[j] = pv ? p1 * (unsigned)a.ld1 * (unsigned)sizeof(T) : kOob;
             abase2[j] = pv ? (mm * (unsigned)a.ld2 - (unsigned)a.c1) * (unsigned)sizeof(T) : kOob;      // indexed by the channel of the concatenation
         } else {
-            const unsigned b = mm / (unsigned)(a.Wo * a.Ho), rem = mm - b * (unsigned)(a.Wo * a.Ho);
-            const unsigned ho = rem / (unsigned)a.Wo, wo = rem - ho * (unsigned)a.Wo;
+            const unsigned b = fdiv(mm, a.d_img), rem = mm - b * (unsigned)(a.Wo * a.Ho);
+            const unsigned ho = fdiv(rem, a.d_row), wo = rem - ho * (unsigned)a.Wo;
             hi0[j] = pv ? (int)ho * a.stride - a.pad : -(1 << 28);       // (a row past the last pixel is never inside the image)
             wi0[j] = (int)wo * a.stride - a.pad;
             abase[j] = b * (unsigned)(a.H * a.W * a.C) * (unsigned)sizeof(T);
@@ -396,7 +412,11 @@ __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* 
 #pragma unroll
             for (int j = 0; j < G::kAPieces; ++j) {
                 const int hi = hi0[j] + kh, wi = wi0[j] + kw;
+#ifdef BF_DIAG_NO_A                                         // (timing experiment only: the pixel tile's pieces fetch nothing, results wrong)
+                const bool ok = false;
+#else
                 const bool ok = live && kh < a.KH && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+#endif
                 const unsigned off = ok ? abase[j] + (unsigned)((hi * a.W + wi) * a.C + c) * (unsigned)sizeof(T) : kOob;
                 lds_void* dst = (lds_void*)(size_t)(slot + (unsigned)((wave + 4 * j) * 1024));
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst, 16, off, 0, 0, 0);
@@ -566,8 +586,9 @@ __device__ __forceinline__ void conv_patch_body(const T* __restrict__ x, const T
     const int wrow = a.wld * (int)sizeof(T), wstride = wrow + 16;               // LDS row pitch of the weights: 36 dwords past a multiple of 64 -> conflict-free reads
     const int w_lds = 32 * wstride;
     const int tiles_x = (a.Wo + PatchGeo::kTW - 1) / PatchGeo::kTW, tiles_y = (a.Ho + PatchGeo::kTH - 1) / PatchGeo::kTH;
-    const int b = blockIdx.x / (tiles_x * tiles_y), trem = blockIdx.x - b * (tiles_x * tiles_y);
-    const int oy0 = (trem / tiles_x) * PatchGeo::kTH, ox0 = (trem % tiles_x) * PatchGeo::kTW;
+    const int b = (int)fdiv(blockIdx.x, a.d_p0), trem = (int)blockIdx.x - b * (tiles_x * tiles_y);
+    const int trow = (int)fdiv((unsigned)trem, a.d_p1);
+    const int oy0 = trow * PatchGeo::kTH, ox0 = (trem - trow * tiles_x) * PatchGeo::kTW;
     const int iy0 = oy0 * a.stride - a.pad, ix0 = ox0 * a.stride - a.pad;
 
     const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, (int)x_bytes, 0x00020000);
@@ -580,7 +601,7 @@ __device__ __forceinline__ void conv_patch_body(const T* __restrict__ x, const T
     const int chunks = PH * PW / kPPC, cpr = PW / kPPC;      // chunks in the patch, per patch row
     for (int p = wave; p * 64 < chunks; p += 4) {
         const int g = p * 64 + lane;
-        const int py = g / cpr, px = (g - py * cpr) * kPPC;
+        const int py = (int)fdiv((unsigned)g, a.d_p2), px = (g - py * cpr) * kPPC;
         const int iy = iy0 + py, ix = ix0 + px;
         const bool ok = g < chunks && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
         const unsigned off = ok ? img + (unsigned)(iy * a.W + ix) * (unsigned)kPix : kOob;
@@ -589,7 +610,7 @@ __device__ __forceinline__ void conv_patch_body(const T* __restrict__ x, const T
     // the weights: LDS position -> (row, byte in the padded row); the pad and rows past the last channel are out-of-range lanes
     for (int p = wave; p * 1024 < w_lds; p += 4) {
         const int g = p * 1024 + lane * 16;
-        const int row = g / wstride, col = g - row * wstride;
+        const int row = (int)fdiv((unsigned)g, a.d_p3), col = g - row * wstride;
         const unsigned off = (g < w_lds && col < wrow && row < a.N) ? (unsigned)(row * wrow + col) : kOob;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(size_t)(lds0 + (unsigned)patch_bytes + (unsigned)(p * 1024)), 16, off, 0, 0, 0);
     }
@@ -911,7 +932,10 @@ hipError_t launch_conv2d_nhwc(int elem_bytes, const void* x, const void* w, cons
     if (C < 4 || (C & (C - 1)) != 0 || ((KW * C) % E) != 0) return hipErrorInvalidValue;       // whole 16-byte chunks per window row
     // float16, C = 4: a chunk is two pixels, which must leave the image together -- even window starts, even width
     if (C < E && ((stride & 1) || (pad & 1) || (W & 1))) return hipErrorInvalidValue;
-    const bool cat = x2 != nullptr || up1 != 0 || ld1 != C;
+    // every 1x1 / stride 1 / unpadded layer takes the "virtual concatenation" kernel, also with one dense source: its addresses are the pixel's base plus
+    // a stage offset -- no pixel decomposition (two integer divisions per piece), no window arithmetic; the short layers are bound by exactly such
+    // vector instructions (a 64 -> 32 channel 1x1 layer: 460 VALU instructions per wave around 4 MFMAs, vector issue 63 % busy)
+    const bool cat = x2 != nullptr || up1 != 0 || ld1 != C || (KH == 1 && KW == 1 && stride == 1 && pad == 0);
     if (cat) {
         if (KH != 1 || KW != 1 || stride != 1 || pad != 0 || c1 < E || c1 > C || (c1 % E) || (ld1 % E) || ld1 < c1) return hipErrorInvalidValue;
         if (c1 < C && (!x2 || (ld2 % E) || ld2 < C - c1 || (reinterpret_cast<uintptr_t>(x2) & 15))) return hipErrorInvalidValue;
@@ -931,6 +955,12 @@ hipError_t launch_conv2d_nhwc(int elem_bytes, const void* x, const void* w, cons
     a.M = (long long)B * a.Ho * a.Wo;
     if (a.M > 0x7fffffffLL) return hipErrorInvalidValue;       // (the kernel splits pixel indices in 32 bits)
     a.x2 = x2; a.c1 = cat ? c1 : C; a.ld1 = cat ? ld1 : C; a.ld2 = ld2; a.up1 = up1;
+    a.d_img = make_fastdiv((unsigned)(a.Ho * a.Wo)); a.d_row = make_fastdiv((unsigned)a.Wo);
+    {
+        const int tx = (a.Wo + 15) / 16, ty = (a.Ho + 7) / 8, ppc = 16 / (4 * elem_bytes), pw = 15 * stride + KW;
+        a.d_p0 = make_fastdiv((unsigned)(tx * ty)); a.d_p1 = make_fastdiv((unsigned)tx);
+        a.d_p2 = make_fastdiv((unsigned)(pw / ppc > 0 ? pw / ppc : 1));
+    }
     // The LDS-DMA kernel addresses its operands through 32-bit buffer offsets with the top bit as the out-of-range mark: every operand tensor
     // below 2 GiB, and a two-source layer switching source on a stage boundary.  BF_CONV_DMA=0 selects the register-staged kernel (A/B runs).
     const int want_dma = conv_dma_switch(-1);
@@ -939,6 +969,7 @@ hipError_t launch_conv2d_nhwc(int elem_bytes, const void* x, const void* w, cons
     const unsigned long long xb = cat ? ((src1_pixels - 1) * (unsigned long long)ld1 + (unsigned long long)a.c1) * eb : src1_pixels * (unsigned long long)C * eb;
     const unsigned long long x2b = (cat && x2) ? (((unsigned long long)B * H * W - 1) * (unsigned long long)ld2 + (unsigned long long)(C - a.c1)) * eb : 0ull;
     a.wld = conv_weight_row(elem_bytes, KH, KW, C);
+    a.d_p3 = make_fastdiv((unsigned)(a.wld * elem_bytes + 16));
     const unsigned long long wb = (unsigned long long)N * (unsigned long long)a.wld * eb;
     const bool dma = want_dma != 0 && xb < 0x7ffffff0ull && x2b < 0x7ffffff0ull && wb < 0x7ffffff0ull && (!(cat && x2) || (a.c1 % (4 * E)) == 0);
     return elem_bytes == 4 ? launch_conv_t<float>(a, x, w, bias, y, cat, dma, (unsigned)xb, (unsigned)x2b, (unsigned)wb, stream)
