@@ -160,9 +160,10 @@ def test_gpu_fused_step_graph_replay(native):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,T,K", [(3, 25200, 1024), (64, 25200, 1024), (2, 700, 1024), (5, 4097, 300), (1, 1024, 1024)])
+@pytest.mark.parametrize("B,T,K", [(3, 25200, 1024), (64, 25200, 1024), (2, 700, 1024), (5, 4097, 300), (1, 1024, 1024), (3, 12000, 1000), (3, 32768, 1024), (3, 40000, 1024)])
 def test_gpu_topk_candidates_match_numpy(native, B, T, K):
-    """bf_topk_candidates_device (radix select + ordered tie admission + bitonic sort, one workgroup per image) against a
+    """bf_topk_candidates_device (radix select + ordered tie admission + bitonic sort, one workgroup per image; keys in registers up to 32,768 boxes
+    per image -- three instantiations -- and re-read from memory above that) against a
     stable NumPy argsort: descending scores, ties by lower box index, gathered boxes / classes, count of positive scores.
     Scores are drawn from a few hundred distinct values (many exact ties, also across the K-th place) plus rejected (-1) boxes."""
     import torch
