@@ -172,19 +172,32 @@ def extras(torch, nat, delays, mics, dev):
     Bf = 64
     win = torch.from_numpy(synth.frame_batch(M, N, Bf)).to(dev)
     cam = torch.randint(0, 256, (Bf, 640, 640, 3), dtype=torch.uint8, device=dev)
-    for half, suffix in ((False, ""), (True, "_fp16_fast_mode")):
-        pipe = FusedPipeline("lerp", 640, dev, half=half)
-        pipe.load_tables(delays, mics)
-        dt = timed(lambda: pipe.step(win, cam), torch, 10)
-        prec = "fp16 (f32 accumulation; narrower than the reference's fp32 predict)" if half else "fp32 (= ultralytics' default predict precision; exact-f32 MFMA)"
-        out["fused_heatmap_overlay_yolo" + suffix] = {"frames_per_s": Bf / dt, "batch": Bf, "image": "640x640x3 uint8", "dtype": "fp16" if half else "fp32",
-                                                      "detector": "YOLOv5s-shaped, %s, random init, 1 class" % prec, "conv_backend": pipe.detector.conv_backend}
-        x = pipe.detector.preprocess(cam)
-        dt = timed(lambda: pipe.detector.postprocess(pipe.detector.raw(x)), torch, 10)
-        out["yolo_only" + suffix] = {"detections_per_s": Bf / dt, "batch": Bf, "gflop_per_frame": 15.8, "dtype": "fp16" if half else "fp32",
-                                     "conv_backend": pipe.detector.conv_backend, "mfma_tflops": 15.8e9 * Bf / dt / 1e12,
-                                     "mfma_peak_tflops": 2500.0 if half else 157.3}
-        del pipe, x
+    # float32 twice: the library's default float32 mode (every operand split exactly into three bfloat16 parts, six products on the bfloat16 matrix
+    # pipes, float32 accumulation: float32 accuracy -- tests/test_detector.py holds it to the same bounds against float64 as the float32 instruction)
+    # and the float32 matrix instruction itself
+    for half, mode, suffix in ((False, 1, ""), (False, 0, "_f32_mfma_instruction"), (True, 1, "_fp16_fast_mode")):
+        initial = nat.lib.bf_conv2d_f32_mode(mode)
+        try:
+            pipe = FusedPipeline("lerp", 640, dev, half=half)
+            pipe.load_tables(delays, mics)
+            dt = timed(lambda: pipe.step(win, cam), torch, 10)
+            if half:
+                prec, how, peak = "fp16 (f32 accumulation; narrower than the reference's fp32 predict)", "v_mfma_f32_32x32x16_f16", 2500.0
+            elif mode == 1:
+                prec, how, peak = ("fp32 (= ultralytics' default predict precision): float32 operands, each split exactly into 3 bfloat16 parts, 6 part products per "
+                                   "product, float32 accumulation", "6 x v_mfma_f32_32x32x16_bf16 per 16 values of K", 2500.0 / 6.0)
+            else:
+                prec, how, peak = "fp32 (= ultralytics' default predict precision), the float32 matrix instruction", "v_mfma_f32_32x32x2_f32", 157.3
+            out["fused_heatmap_overlay_yolo" + suffix] = {"frames_per_s": Bf / dt, "batch": Bf, "image": "640x640x3 uint8", "dtype": "fp16" if half else "fp32",
+                                                          "detector": "YOLOv5s-shaped, %s, random init, 1 class" % prec, "conv_backend": pipe.detector.conv_backend}
+            x = pipe.detector.preprocess(cam)
+            dt = timed(lambda: pipe.detector.postprocess(pipe.detector.raw(x)), torch, 10)
+            out["yolo_only" + suffix] = {"detections_per_s": Bf / dt, "batch": Bf, "gflop_per_frame": 15.8, "dtype": "fp16" if half else "fp32",
+                                         "conv_backend": pipe.detector.conv_backend, "matrix_instruction": how, "mfma_tflops": 15.8e9 * Bf / dt / 1e12,
+                                         "mfma_peak_tflops": peak}
+            del pipe, x
+        finally:
+            nat.lib.bf_conv2d_f32_mode(initial)
     # config 3 + frequency-domain DAS: same 64-mic array and 101x101 grid through the frequency-domain geometry
     old = (C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y)
     C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y = 64, 1, 101, 101

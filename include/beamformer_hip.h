@@ -259,6 +259,11 @@ int bf_conv2d_weight_row(int kh, int kw, int c);
  *       every operand tensor is smaller than 2 GiB) or through registers.  enable = 1 / 0 selects (2: as 1, and the stem's patch kernel in either precision), < 0 only asks; returns the previous setting
  *       ($BF_CONV_DMA=0 sets the initial one).  Results of the two are bit-identical (same products, same summation order). */
 int bf_conv2d_use_dma_kernel(int enable);
+/*   bf_conv2d_f32_mode: how the float32 LDS-DMA convolution kernels multiply.  0 = the float32 matrix instruction on the operands as they are
+ *       (v_mfma_f32_32x32x2_f32); 1 = every operand value split exactly into three bfloat16 parts and the product accumulated (in float32) from the
+ *       six part products that matter (v_mfma_f32_32x32x16_bf16): float32 accuracy -- measured against float64 in tests/test_detector.py -- at
+ *       2.67 x the matrix rate.  mode < 0 only asks; returns the previous setting ($BF_CONV_F32=native|split sets the initial one). */
+int bf_conv2d_f32_mode(int mode);
 int bf_conv2d_nhwc_f16_device(const void *d_x, const void *d_w, const float *d_bias, void *d_y, int batch, int h, int w, int c, int n, int kh, int kw,
                               int stride, int pad, int silu, void *stream);
 /*   bf_conv2d_nhwc_f16_into_device: the same, writing into a channel slice of a wider NHWC buffer -- d_y points at the slice's first
@@ -268,8 +273,9 @@ int bf_conv2d_nhwc_f16_device(const void *d_x, const void *d_w, const float *d_b
 int bf_conv2d_nhwc_f16_into_device(const void *d_x, const void *d_w, const float *d_bias, void *d_y, int ldy, const void *d_res, int ldr, int batch, int h,
                                    int w, int c, int n, int kh, int kw, int stride, int pad, int silu, void *stream);
 /*   float32 forms of the detector's tensor kernels -- the precision ultralytics' predict runs at by default
- *       (yolo_smooth_tracking.py:13-23 passes no half=): the same kernels on float32 NHWC tensors, the convolution on the exact-f32 matrix
- *       instruction v_mfma_f32_32x32x2_f32 (products and sums in f32, one rounding per product), SiLU as x / (1 + expf(-x)).
+ *       (yolo_smooth_tracking.py:13-23 passes no half=): the same kernels on float32 NHWC tensors, the convolution's products exact and its sums in f32 in either
+ *       float32 mode (bf_conv2d_f32_mode above: three-way bfloat16 operand split on v_mfma_f32_32x32x16_bf16, the default, or v_mfma_f32_32x32x2_f32),
+ *       SiLU as x / (1 + expf(-x)).
  *       Weight rows are padded to a multiple of 32 floats (bf_conv2d_weight_row_f32); c a power of two >= 4. */
 int bf_conv2d_weight_row_f32(int kh, int kw, int c);
 int bf_conv2d_nhwc_f32_device(const void *d_x, const void *d_w, const float *d_bias, void *d_y, int batch, int h, int w, int c, int n, int kh, int kw,

@@ -195,6 +195,20 @@ def test_gpu_topk_candidates_match_numpy(native, B, T, K):
 
 # ---- the detector's convolutions as this library's implicit-GEMM kernel (csrc/conv_kernels.hip)
 
+import contextlib
+
+
+@contextlib.contextmanager
+def f32_mode(native, mode):
+    """bf_conv2d_f32_mode for the duration of a block: 0 = the float32 matrix instruction (LDS-DMA and register-staged kernels then multiply and add in the same
+    order: bit-identical results), 1 = the three-way bfloat16 split (the library's default; LDS-DMA kernels only, so identity across kernels is not a property)."""
+    initial = native.lib.bf_conv2d_f32_mode(mode)
+    try:
+        yield
+    finally:
+        native.lib.bf_conv2d_f32_mode(initial)
+
+
 CONV_CASES = [  # (B, Cin, H, W, Cout, k, stride, pad, silu)      the layer shapes of yolov5s.py plus ragged tiles
     (2, 3, 64, 96, 32, 6, 2, 2, True),        # the stem: 3 channels padded to 4, 6x6 window, stride 2 (the patch kernel)
     (1, 3, 70, 100, 32, 6, 2, 2, True),       # the stem on a picture whose 35 x 50 outputs leave ragged 8 x 16 pixel blocks
@@ -242,7 +256,7 @@ def test_gpu_hip_convolution_matches_torch_fp32(native, B, C, H, W, N, k, s, p, 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,C,H,W,N,k,s,p,silu", CONV_CASES)
 def test_gpu_hip_convolution_f32_matches_fp64(native, B, C, H, W, N, k, s, p, silu):
-    """bf_conv2d_nhwc_f32_device (exact-f32 MFMA) against a float64 convolution of the same float32 operands on the CPU, and against
+    """bf_conv2d_nhwc_f32_device (both float32 modes: the exact-f32 MFMA and the three-way bfloat16 split) against a float64 convolution of the same float32 operands on the CPU, and against
     torch's own float32 convolution on the GPU: 1e-5 of the layer's largest output is the bar; the kernel sits
     an order of magnitude inside it."""
     import torch
@@ -259,27 +273,37 @@ def test_gpu_hip_convolution_f32_matches_fp64(native, B, C, H, W, N, k, s, p, si
     conv = conv.cuda()
     xg = x.cuda().contiguous(memory_format=torch.channels_last)
     hc = yolov5s.HipConv(conv, silu)
-    got = hc(xg)                                       # the default kernel: operand tiles by LDS-DMA
-    assert native.lib.bf_conv2d_use_dma_kernel(0) == 1
-    try:
-        assert torch.equal(got, hc(xg))                # the register-staged kernel: the same products in the same order
-    finally:
-        native.lib.bf_conv2d_use_dma_kernel(1)
-    if C == 3:                                         # the stem's patch kernel is the default in float16 only: the same bits from it in float32
-        assert native.lib.bf_conv2d_use_dma_kernel(2) == 1
-        try:
-            assert torch.equal(got, hc(xg))
-        finally:
-            native.lib.bf_conv2d_use_dma_kernel(1)
     want32 = torch.nn.functional.conv2d(xg, conv.weight, conv.bias, s, p)
     if silu:
         want32 = torch.nn.functional.silu(want32)
-    assert got.shape == want64.shape and got.dtype == torch.float32 and got.is_contiguous(memory_format=torch.channels_last)
     top = want64.abs().max().item()
-    e64 = (got.double().cpu() - want64).abs().max().item() / top
-    e32 = (got - want32).abs().max().item() / top
-    assert e64 < 5e-6, e64
-    assert e32 < 1e-5, e32
+    initial = native.lib.bf_conv2d_f32_mode(0)
+    try:
+        got = hc(xg)                                       # the native float32 matrix instruction; operand tiles by LDS-DMA
+        assert native.lib.bf_conv2d_use_dma_kernel(0) == 1
+        try:
+            assert torch.equal(got, hc(xg))                # the register-staged kernel: the same products in the same order
+        finally:
+            native.lib.bf_conv2d_use_dma_kernel(1)
+        if C == 3:                                         # the stem's patch kernel is the default in float16 only: the same bits from it in float32
+            assert native.lib.bf_conv2d_use_dma_kernel(2) == 1
+            try:
+                assert torch.equal(got, hc(xg))
+            finally:
+                native.lib.bf_conv2d_use_dma_kernel(1)
+        native.lib.bf_conv2d_f32_mode(1)
+        split = hc(xg)                                     # three-way bfloat16 split of both operands, six products: float32 accuracy on the bfloat16 pipes
+    finally:
+        native.lib.bf_conv2d_f32_mode(initial)
+    for name, out in (("native", got), ("split", split)):
+        assert out.shape == want64.shape and out.dtype == torch.float32 and out.is_contiguous(memory_format=torch.channels_last)
+        e64 = (out.double().cpu() - want64).abs().max().item() / top
+        e32 = (out - want32).abs().max().item() / top
+        assert e64 < 5e-6, (name, e64)
+        assert e32 < 1e-5, (name, e32)
+    e_native = (got.double().cpu() - want64).abs().max().item() / top
+    e_split = (split.double().cpu() - want64).abs().max().item() / top
+    assert e_split <= 2.0 * e_native + 2e-7, (e_split, e_native)      # the split is as accurate as the float32 instruction (usually more: exact products)
 
 
 @pytest.mark.gpu
@@ -323,14 +347,18 @@ def test_gpu_hip_convolution_without_bias_and_with_a_ragged_channel_count(native
         conv = conv.cuda().to(dt)
         x = torch.randn((2, 64, 18, 22), generator=g).cuda().to(dt).contiguous(memory_format=torch.channels_last)
         hc = yolov5s.HipConv(conv, False)
-        got = hc(x)
-        native.lib.bf_conv2d_use_dma_kernel(0)
-        try:
-            assert torch.equal(got, hc(x))
-        finally:
-            native.lib.bf_conv2d_use_dma_kernel(1)
         want = torch.nn.functional.conv2d(x.float(), conv.weight.float(), None if conv.bias is None else conv.bias.float(), 1, 1)
+        with f32_mode(native, 0):
+            got = hc(x)
+            native.lib.bf_conv2d_use_dma_kernel(0)
+            try:
+                assert torch.equal(got, hc(x))
+            finally:
+                native.lib.bf_conv2d_use_dma_kernel(1)
         assert (got.float() - want).abs().max().item() / want.abs().max().item() < (2e-3 if half else 1e-5)
+        with f32_mode(native, 1):
+            split = hc(x)
+        assert (split.float() - want).abs().max().item() / want.abs().max().item() < (2e-3 if half else 1e-5)
 
 
 @pytest.mark.gpu
@@ -355,26 +383,35 @@ def test_gpu_hip_1x1_over_a_virtual_concatenation(native, half, up):
     a, b = big_a[:, 8:], big_b[:, :c2]                 # channel slices: pixel pitch wider than the channel count, offset bases
     full = torch.cat((torch.nn.functional.interpolate(a, scale_factor=2, mode="nearest") if up else a, b), 1).contiguous(memory_format=cl)
     res = torch.randn((B, N, H, W), generator=g).cuda().to(dt).contiguous(memory_format=cl)
-    want = hc(full, residual=res)
-    buf = torch.full((B, N + 8, H, W), 3.0, dtype=dt, device="cuda").contiguous(memory_format=cl)
-    got = hc(a, x2=b, up=up, out=buf[:, 8:], residual=res)
-    assert got.data_ptr() == buf[:, 8:].data_ptr()
-    assert torch.equal(buf[:, 8:], want) and bool((buf[:, :8] == 3.0).all())
     ref = torch.nn.functional.silu(torch.nn.functional.conv2d(full.float(), conv.weight.cuda().to(dt).float(), conv.bias.cuda().float())) + res.float()
-    assert (want.float() - ref).abs().max().item() / ref.abs().max().item() < (2e-3 if half else 1e-5)
-    one = hc(full[:, : c1 + c2])                       # a single dense source through the plain entry
-    assert torch.equal(one, hc(full[:, :c1], x2=full[:, c1:]))
-    # c1 = 48 channels is not a whole 64-byte stage for float16: that call ran on the register-staged kernel.  Sources that meet on a stage
-    # edge (32 + 32 channels) take the LDS-DMA kernel in both precisions: the same answer from both kernels and from the materialised tensor.
     a2, b2 = big_a[:, 8:40], res[:, :32]
     full2 = torch.cat((torch.nn.functional.interpolate(a2, scale_factor=2, mode="nearest") if up else a2, b2), 1).contiguous(memory_format=cl)
-    d1 = hc(a2, x2=b2, up=up)
-    assert native.lib.bf_conv2d_use_dma_kernel(0) == 1
-    try:
-        d0 = hc(a2, x2=b2, up=up)
-    finally:
-        native.lib.bf_conv2d_use_dma_kernel(1)
-    assert torch.equal(d1, d0) and torch.equal(d1, hc(full2))
+    with f32_mode(native, 0):                           # (float16 is not touched by the mode; float32 identities hold on the float32 instruction)
+        want = hc(full, residual=res)
+        buf = torch.full((B, N + 8, H, W), 3.0, dtype=dt, device="cuda").contiguous(memory_format=cl)
+        got = hc(a, x2=b, up=up, out=buf[:, 8:], residual=res)
+        assert got.data_ptr() == buf[:, 8:].data_ptr()
+        assert torch.equal(buf[:, 8:], want) and bool((buf[:, :8] == 3.0).all())
+        assert (want.float() - ref).abs().max().item() / ref.abs().max().item() < (2e-3 if half else 1e-5)
+        one = hc(full[:, : c1 + c2])                       # a single dense source through the plain entry
+        assert torch.equal(one, hc(full[:, :c1], x2=full[:, c1:]))
+        # c1 = 48 channels is not a whole 64-byte stage for float16: that call ran on the register-staged kernel.  Sources that meet on a stage
+        # edge (32 + 32 channels) take the LDS-DMA kernel in both precisions: the same answer from both kernels and from the materialised tensor.
+        d1 = hc(a2, x2=b2, up=up)
+        assert native.lib.bf_conv2d_use_dma_kernel(0) == 1
+        try:
+            d0 = hc(a2, x2=b2, up=up)
+        finally:
+            native.lib.bf_conv2d_use_dma_kernel(1)
+        assert torch.equal(d1, d0) and torch.equal(d1, hc(full2))
+    if not half:
+        with f32_mode(native, 1):                       # the split mode: the same calls, the same answers to float32 accuracy, and identical between the two addressings
+            buf2 = torch.full((B, N + 8, H, W), 3.0, dtype=dt, device="cuda").contiguous(memory_format=cl)
+            got2 = hc(a, x2=b, up=up, out=buf2[:, 8:], residual=res)
+            assert (got2.float() - ref).abs().max().item() / ref.abs().max().item() < 1e-5 and bool((buf2[:, :8] == 3.0).all())
+            d2 = hc(a2, x2=b2, up=up)
+            assert torch.equal(d2, hc(full2))
+            assert (d2 - d1).abs().max().item() / d1.abs().max().item() < 1e-5
     with pytest.raises(Exception):
         yolov5s.HipConv(torch.nn.Conv2d(64, 8, 3, padding=1).cuda().to(dt), True)(torch.zeros((1, 32, 4, 4), dtype=dt, device="cuda"), x2=torch.zeros((1, 32, 4, 4), dtype=dt, device="cuda"))
 

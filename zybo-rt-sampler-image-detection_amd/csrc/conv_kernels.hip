@@ -26,6 +26,7 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 
 #include "das_kernels.h"
 
@@ -74,6 +75,7 @@ struct ConvArgs {
     const void* x2;
     int c1, ld1, ld2, up1;
     int wld;              // elements between consecutive weight rows (rows are zero-padded to whole 128-byte stages)
+    int fast_tap;         // LDS-DMA kernels, window path: every stage lies inside one (kh, kw) tap (C elements >= a stage row) and KH * KW <= 32
     FastDiv d_img, d_row; // by Ho * Wo (pixel -> image) and by Wo (-> row)
     FastDiv d_p0, d_p1, d_p2, d_p3;   // the patch kernel's: tiles per image, tiles per tile row, chunks per patch row, bytes per padded weight row
 };
@@ -292,7 +294,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const T* __restrict__ x
 typedef __attribute__((address_space(3))) void lds_void;
 constexpr unsigned kOob = 0x80000000u;
 
-template <typename T, int kBM_, int kBN, int kCPR> struct DmaGeo {
+template <typename T, int kBM_, int kBN, int kCPR, bool kSplit = false> struct DmaGeo {
     // kCPR: 16-byte chunks of K per row and stage -- 4 (64-byte rows) or 8 (128-byte rows: every row of a piece is one full cache line, half the
     // barriers and address computations per byte; float16).
     // Ring depth: a float32 stage carries 32 MFMAs of 64 cycles per wave (one stage of loads in flight covers the memory latency, and the smaller
@@ -306,7 +308,8 @@ template <typename T, int kBM_, int kBN, int kCPR> struct DmaGeo {
 #ifndef BF_F16_DEPTH
 #define BF_F16_DEPTH 3
 #endif
-    static constexpr int kDepth = sizeof(T) == 4 ? BF_F32_DEPTH : (kCPR == 4 ? BF_F16_DEPTH : (3 * kStageBytes_ <= 80 * 1024 ? 3 : 2));
+    // (kSplit: float32 operands on the bfloat16 pipes, below -- a stage is 6 MFMAs of 32 cycles per tile, as short as a float16 one)
+    static constexpr int kDepth = sizeof(T) == 4 && !kSplit ? BF_F32_DEPTH : (kCPR == 4 ? BF_F16_DEPTH : (3 * kStageBytes_ <= 80 * 1024 ? 3 : 2));
     static constexpr int kRingBytes = kDepth * kStageBytes_;
     static constexpr int kPieceRows = 64 / kCPR;                        // a 1-KiB piece = kPieceRows rows; piece p of a tile belongs to wave p % 4
     static constexpr bool kHalfB = kBN / kPieceRows < 4;                // (32 channels, 64-byte rows: two pieces, issued as four half pieces)
@@ -325,14 +328,58 @@ template <typename T, int kBM_, int kBN, int kCPR> struct DmaGeo {
 
 // (The body lives in a __device__ function: the buffer-descriptor type of the LDS-DMA builtins does not exist in the host pass, and a kernel whose
 //  body the host pass cannot parse gets no launch stub; a __device__ function's host-side diagnostics are deferred and dropped.)
-template <typename T, int kBM_, int kBN, int kCPR, bool kCat>
+// kSplit (float32 only): the products run on the bfloat16 matrix pipes at float32 accuracy.  Every operand x is split exactly into three bfloat16
+// parts, x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (round to nearest; the differences are exact in float32; what is
+// left after l is below 2^-24 |x|), and a product a b is accumulated as the six part products of order up to 2^-16:
+// l_a h_b, h_a l_b, m_a m_b, m_a h_b, h_a m_b, h_a h_b (each exact: 8 x 8 significand bits; the three dropped ones are below 2^-24 |a b|, the size of
+// the float32 rounding of the sum itself).  Accumulation is the MFMA's float32, as in the native kernel.  Six v_mfma_f32_32x32x16_bf16 of 32 cycles
+// replace eight v_mfma_f32_32x32x2_f32 of 64 cycles for the same 16 values of K: 2.67 x the matrix rate; the price is 4.5 vector instructions per
+// operand value for the split.  Measured against float64 (tests/test_detector.py) the error is at or below the native float32 kernel's.
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+struct Split3 { uint4v h, m, l; };
+
+// (The differences are single v_sub_f32: hipcc pairs them into v_pk_add_f32 when it can, and that instruction neither runs in the shadow of an MFMA nor
+//  at the rate of two plain ones -- scripts/dev/mfma_valu_probe.hip: 24 MFMAs interleaved with 144 v_add_f32 take 1.38 x the MFMAs' own time at one wave
+//  per SIMD and 1.2 x at two, with 144 v_pk_add_f32 2.2 x.)
+__device__ __forceinline__ float sub_f32(float a, float b)
+{
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ Split3 split3(const float4v& p, const float4v& q)       // eight float32 values -> three vectors of eight bfloat16
+{
+    Split3 r;
+#ifdef BF_DIAG_NO_SPLIT                                      // (timing experiment only: the operand bits as they are, results wrong)
+    r.h = __builtin_bit_cast(uint4v, p); r.m = __builtin_bit_cast(uint4v, q); r.l = r.h ^ r.m;
+    return r;
+#endif
+    const float2v v[4] = {{p[0], p[1]}, {p[2], p[3]}, {q[0], q[1]}, {q[2], q[3]}};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(v[i], bf16x2v));
+        const float2v r1 = {sub_f32(v[i][0], __uint_as_float(h << 16)), sub_f32(v[i][1], __uint_as_float(h & 0xffff0000u))};
+        const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2v));
+        const float2v r2 = {sub_f32(r1[0], __uint_as_float(m << 16)), sub_f32(r1[1], __uint_as_float(m & 0xffff0000u))};
+        r.h[i] = h; r.m[i] = m;
+        r.l[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2v));
+    }
+    return r;
+}
+
+template <typename T, int kBM_, int kBN, int kCPR, bool kCat, bool kSplit = false>
 __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y, const ConvArgs& a,
                                               unsigned x_bytes, unsigned x2_bytes, unsigned w_bytes)
 {
     typedef typename Elem<T>::vec vec;
-    typedef DmaGeo<T, kBM_, kBN, kCPR> G;
+    typedef DmaGeo<T, kBM_, kBN, kCPR, kSplit> G;
     constexpr int E = Elem<T>::E;
     constexpr bool kF32 = sizeof(T) == 4;
+    static_assert(!kSplit || kF32, "the split is a float32 mode");
     constexpr int kWM = G::kWM, kTM = G::kTM, kTN = G::kTN;
     constexpr int kCRow = G::kCCols + E;
     constexpr int kTileBytes = kBM_ * kCRow * (int)sizeof(T);
@@ -383,6 +430,29 @@ __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* 
     }
     // the chunk's position in K: kh and the chunk index inside the kh run, advanced by kCPR chunks per stage
     int kh = ck / cpk, kk = ck - kh * cpk;
+    // The cheap form of the per-stage addresses.  Window path with a.fast_tap: the kCPR chunks of a stage share their tap (kh, kw), so a lane's offset is
+    //   [pixel base + ((hi0 W + wi0) C + ck E) bytes]  +  [((kh W + kw) C + c0) bytes]  =  lbase (per lane, fixed)  +  a wave-uniform term per stage,
+    // and whether the tap falls inside the picture is bit (kh KW + kw) of a per-lane mask made once (nmask: 1 = outside): shifted to bit 31 and or-ed into
+    // the offset it sends the lane past every tensor this kernel accepts -- three vector instructions per piece and stage where the general form (below,
+    // kept for layers of fewer channels than a stage row) takes about twenty.  kCat: the chunk's 16 bytes fold into the bases, a stage adds kCPR * 16.
+    unsigned lbase[G::kAPieces], nmask[G::kAPieces];
+    int s_kh = 0, s_kw = 0, s_c0 = 0;                         // (wave-uniform) tap and first channel of the stage about to be issued
+#pragma unroll
+    for (int j = 0; j < G::kAPieces; ++j) { lbase[j] = 0u; nmask[j] = 0xffffffffu; }
+    if constexpr (kCat) {
+#pragma unroll
+        for (int j = 0; j < G::kAPieces; ++j) { abase[j] += 16u * (unsigned)ck; abase2[j] += 16u * (unsigned)ck; }      // (kOob stays past 2^31)
+    } else if (a.fast_tap) {
+#pragma unroll
+        for (int j = 0; j < G::kAPieces; ++j) {
+            lbase[j] = abase[j] + (((unsigned)hi0[j] * (unsigned)a.W + (unsigned)wi0[j]) * (unsigned)a.C + (unsigned)(ck * E)) * (unsigned)sizeof(T);
+            unsigned inside = 0u;
+            for (int th = 0; th < a.KH; ++th)
+                for (int tw = 0; tw < a.KW; ++tw)
+                    if ((unsigned)(hi0[j] + th) < (unsigned)a.H && (unsigned)(wi0[j] + tw) < (unsigned)a.W) inside |= 1u << (th * a.KW + tw);
+            nmask[j] = ~inside;
+        }
+    }
     // Weight tile: the same pieces over its kBN rows (kHalfB: waves fill rows [8 wave, 8 wave + 8) with their lanes 0..31)
     unsigned wbase[G::kBPieces];
 #pragma unroll
@@ -395,18 +465,35 @@ __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* 
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
 
     auto issue = [&](int s, int ring) {   // the DMA pieces of stage s into ring slot `ring` (past the last stage: out-of-range lanes only, zeros nobody reads)
+#ifdef BF_DIAG_NO_ISSUE                                      // (timing experiment only: nothing is fetched, results wrong)
+        return;
+#endif
         const unsigned slot = lds0 + (unsigned)(ring * G::kStageBytes_);
         const bool live = s < n_stage;
         if constexpr (kCat) {
-            const int c = (kCPR * s + ck) * E;             // chunk = channels [c, c + E) of the concatenation; a stage lies in one source (c1 % (kCPR E) == 0)
+            // chunk kCPR s + ck = channels [(kCPR s + ck) E, + E) of the concatenation; a stage lies in one source (c1 % (kCPR E) == 0)
             const bool second = kCPR * s * E >= a.c1;
+            const int left = n_chunk - kCPR * s;           // chunks of K from this stage on (only the last stage can have fewer than kCPR)
+            const unsigned u = (unsigned)(s * RB);
 #pragma unroll
             for (int j = 0; j < G::kAPieces; ++j) {
-                const unsigned off = (live && kCPR * s + ck < n_chunk) ? (second ? abase2[j] : abase[j]) + (unsigned)c * (unsigned)sizeof(T) : kOob;
+                unsigned off = live ? (second ? abase2[j] : abase[j]) + u : kOob;
+                if (left < kCPR && ck >= left) off = kOob;
                 lds_void* dst = (lds_void*)(size_t)(slot + (unsigned)((wave + 4 * j) * 1024));
                 if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, dst, 16, off, 0, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst, 16, off, 0, 0, 0);
             }
+        } else if (a.fast_tap) {
+            const unsigned u = live ? (unsigned)(((s_kh * a.W + s_kw) * a.C + s_c0) * (int)sizeof(T)) : kOob;
+            const int sh = live ? 31 - (s_kh * a.KW + s_kw) : 0;          // (past the last stage: bit 31 comes from u, whatever the mask says)
+#pragma unroll
+            for (int j = 0; j < G::kAPieces; ++j) {
+                const unsigned off = live ? (((nmask[j] << sh) & 0x80000000u) | (lbase[j] + u)) : kOob;
+                lds_void* dst = (lds_void*)(size_t)(slot + (unsigned)((wave + 4 * j) * 1024));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst, 16, off, 0, 0, 0);
+            }
+            s_c0 += kCPR * E;
+            if (s_c0 >= a.C) { s_c0 = 0; if (++s_kw == a.KW) { s_kw = 0; ++s_kh; } }
         } else {
             const int ke = kk * E, kw = ke >> a.c_shift, c = ke & (a.C - 1);
 #pragma unroll
@@ -473,6 +560,24 @@ __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* 
 #ifdef BF_CONV_PRIO
         __builtin_amdgcn_s_setprio(BF_CONV_PRIO);
 #endif
+        if constexpr (kSplit) {
+#pragma unroll
+            for (int k4 = 0; k4 < kCPR / 4; ++k4) {            // 16 values of K: this lane's two chunks of every row
+                Split3 as[kTM], bs[kTN];
+#pragma unroll
+                for (int i = 0; i < kTM; ++i)
+                    as[i] = split3(*reinterpret_cast<const float4v*>(st + fa + 32 * RB * i + fo[2 * k4]), *reinterpret_cast<const float4v*>(st + fa + 32 * RB * i + fo[2 * k4 + 1]));
+#pragma unroll
+                for (int t = 0; t < kTN; ++t)
+                    bs[t] = split3(*reinterpret_cast<const float4v*>(st + fb + 32 * RB * t + fo[2 * k4]), *reinterpret_cast<const float4v*>(st + fb + 32 * RB * t + fo[2 * k4 + 1]));
+#define BF_SPLIT_MFMA(P, Q)                                                                                                                          \
+                _Pragma("unroll") for (int i = 0; i < kTM; ++i)                                                                                      \
+                    _Pragma("unroll") for (int t = 0; t < kTN; ++t)                                                                                  \
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8v, as[i].P), __builtin_bit_cast(bf16x8v, bs[t].Q), acc[i][t], 0, 0, 0)
+                BF_SPLIT_MFMA(l, h); BF_SPLIT_MFMA(h, l); BF_SPLIT_MFMA(m, m); BF_SPLIT_MFMA(m, h); BF_SPLIT_MFMA(h, m); BF_SPLIT_MFMA(h, h);
+#undef BF_SPLIT_MFMA
+            }
+        } else {
 #pragma unroll
         for (int k2 = 0; k2 < kCPR / 2; ++k2) {
             vec af[kTM], bf[kTN];
@@ -493,6 +598,7 @@ __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* 
 #pragma unroll
                     for (int t = 0; t < kTN; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[t], acc[i][t], 0, 0, 0);
             }
+        }
         }
 #ifdef BF_CONV_PRIO
         __builtin_amdgcn_s_setprio(0);
@@ -549,11 +655,11 @@ __device__ __forceinline__ void conv_dma_body(const T* __restrict__ x, const T* 
     }
 }
 
-template <typename T, int kBM_, int kBN, int kCPR, bool kCat>
+template <typename T, int kBM_, int kBN, int kCPR, bool kCat, bool kSplit = false>
 __global__ void __launch_bounds__(256) conv_dma_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y, ConvArgs a,
                                                        unsigned x_bytes, unsigned x2_bytes, unsigned w_bytes)
 {
-    conv_dma_body<T, kBM_, kBN, kCPR, kCat>(x, w, bias, y, a, x_bytes, x2_bytes, w_bytes);
+    conv_dma_body<T, kBM_, kBN, kCPR, kCat, kSplit>(x, w, bias, y, a, x_bytes, x2_bytes, w_bytes);
 }
 
 // ---- The stem (the network's first layer: 6x6 window, stride 2, 4 input channels after padding, 32 output channels) as a PATCH kernel.
@@ -785,11 +891,14 @@ __global__ void __launch_bounds__(256) upsample_concat_kernel(const uint4* __res
 // ceil(workgroups / CUs) x area x (1 + thin / rows + thin / columns) wins.  `thin` prices what a smaller tile moves per MFMA: almost nothing
 // next to a 64-cycle float32 MFMA (profiles/r03_conv_layers_f32.csv: 64 x 64 tiles win on most layers through the finer split alone), a lot next
 // to a float16 one, whose 128 x 128 tile already keeps the LDS port 3/4 busy (measured: 64 x 64 tiles there run at 0.15 of the matrix peak).
+#ifndef BF_CONV_F32_DEFAULT
+#define BF_CONV_F32_DEFAULT 1
+#endif
 struct DmaTile { int bm, bn; };
-inline DmaTile pick_dma_tile(long long M, int N, int n_cus, bool f32)
+inline DmaTile pick_dma_tile(long long M, int N, int n_cus, bool f32, bool split = false)
 {
     static const DmaTile shapes[] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 32}};
-    const double thin = f32 ? 8.0 : 160.0;
+    const double thin = f32 && !split ? 8.0 : 160.0;       // (the split float32 mode multiplies like float16: measured 8 / 24 / 64 / 160 -> 8.82 / 8.28 / 8.13 / 8.12 ms for the 60 layers)
     DmaTile best{128, N >= 128 ? 128 : (N <= 32 ? 32 : 64)};
     double best_cost = 1e300;
     for (const DmaTile& t : shapes) {
@@ -833,7 +942,8 @@ hipError_t launch_conv_t(const ConvArgs& a, const void* x, const void* w, const 
                 return hipGetLastError();
             }
         }
-        const DmaTile t = pick_dma_tile(a.M, a.N, n_cus, sizeof(T) == 4);
+        const bool split = sizeof(T) == 4 && conv_f32_mode(-1) == 1;
+        const DmaTile t = pick_dma_tile(a.M, a.N, n_cus, sizeof(T) == 4 && !split, split);
         // Rows of 128 bytes (full cache lines per row, half the barriers per MFMA) pay where stages are many and the tile is 128 channels wide: float16
         // layers of 128+ channels with K >= 1024, or 1x1 layers with K >= 512 (profiles/r03_conv_layers_f16.csv; the stem and the 32- / 64-channel layers
         // lose to the coarser K padding and the smaller ring).  float32 stages are long as they are: 64-byte rows.  $BF_CONV_ROW=64|128 forces either.
@@ -841,13 +951,19 @@ hipError_t launch_conv_t(const ConvArgs& a, const void* x, const void* w, const 
         const int K = a.KH * a.KW * a.C;
         bool wide_rows = row_env == 128 ? true : (row_env == 64 ? false : (sizeof(T) == 2 && a.N >= 128 && (K >= 1024 || (a.KH == 1 && K >= 512))));
         if (cat && a.x2 && (a.c1 % (8 * (16 / (int)sizeof(T)))) != 0) wide_rows = false;
-#define BF_DMA_LAUNCH(BM, BN, CPR, CAT)                                                                                                                          \
-        hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, CPR, CAT>), dim3((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN)), dim3(256), 0, stream,  \
-                           xp, wp, bias, yp, a, x_bytes, x2_bytes, w_bytes)
+        ConvArgs af = a;                                       // (see ConvArgs::fast_tap; $BF_CONV_TAP=0 keeps the general address form, for A/B runs)
+        static const int tap_env = [] { const char* e = getenv("BF_CONV_TAP"); return e ? atoi(e) : 1; }();
+        af.fast_tap = (tap_env != 0 && !cat && a.C / (16 / (int)sizeof(T)) >= ((wide_rows && !split) ? 8 : 4) && a.KH * a.KW <= 32) ? 1 : 0;
+#define BF_DMA_LAUNCH(BM, BN, CPR, CAT, SPLIT)                                                                                                                          \
+        hipLaunchKernelGGL((conv_dma_kernel<T, BM, BN, CPR, CAT, SPLIT>), dim3((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN)), dim3(256), 0, stream,  \
+                           xp, wp, bias, yp, af, x_bytes, x2_bytes, w_bytes)
 #define BF_DMA_PICK(BM, BN)                                                                                                    \
         do {                                                                                                                   \
-            if (wide_rows) { if (cat) BF_DMA_LAUNCH(BM, BN, 8, true); else BF_DMA_LAUNCH(BM, BN, 8, false); }                  \
-            else { if (cat) BF_DMA_LAUNCH(BM, BN, 4, true); else BF_DMA_LAUNCH(BM, BN, 4, false); }                            \
+            if constexpr (sizeof(T) == 4) {                                                                                    \
+                if (split) { if (cat) BF_DMA_LAUNCH(BM, BN, 4, true, true); else BF_DMA_LAUNCH(BM, BN, 4, false, true); break; } \
+            }                                                                                                                  \
+            if (wide_rows) { if (cat) BF_DMA_LAUNCH(BM, BN, 8, true, false); else BF_DMA_LAUNCH(BM, BN, 8, false, false); }    \
+            else { if (cat) BF_DMA_LAUNCH(BM, BN, 4, true, false); else BF_DMA_LAUNCH(BM, BN, 4, false, false); }              \
         } while (0)
         if (t.bm == 128 && t.bn == 128) BF_DMA_PICK(128, 128);
         else if (t.bm == 128 && t.bn == 64) BF_DMA_PICK(128, 64);
@@ -920,6 +1036,17 @@ int conv_dma_switch(int value)
     return old;
 }
 
+// How the float32 LDS-DMA kernels multiply: 0 = v_mfma_f32_32x32x2_f32 on the operands as they are, 1 = three-way bfloat16 split of both operands and
+// six v_mfma_f32_32x32x16_bf16 per product (conv_dma_body; same accuracy, 2.67 x the matrix rate).  $BF_CONV_F32=native|split sets the initial mode;
+// value < 0 only reads.  Returns the previous setting.  (The register-staged kernel and the stem's patch kernel are native only.)
+int conv_f32_mode(int value)
+{
+    static int state = [] { const char* e = getenv("BF_CONV_F32"); return e ? (strcmp(e, "split") == 0 ? 1 : 0) : BF_CONV_F32_DEFAULT; }();
+    const int old = state;
+    if (value >= 0) state = value != 0 ? 1 : 0;
+    return old;
+}
+
 // elem_bytes: 2 (float16) or 4 (float32).  x2 != nullptr or ld1 != C or up1: the 1x1 window over a virtual concatenation (ConvArgs).
 hipError_t launch_conv2d_nhwc(int elem_bytes, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C, int N, int KH, int KW,
                               int stride, int pad, int act, int ldy, const void* res, int ldr, const void* x2, int c1, int ld1, int ld2, int up1,
@@ -947,7 +1074,7 @@ hipError_t launch_conv2d_nhwc(int elem_bytes, const void* x, const void* w, cons
     a.Ho = (H + 2 * pad - KH) / stride + 1;
     a.Wo = (W + 2 * pad - KW) / stride + 1;
     if (a.Ho <= 0 || a.Wo <= 0) return hipErrorInvalidValue;
-    a.ldy = ldy; a.ldr = ldr; a.res = res;
+    a.ldy = ldy; a.ldr = ldr; a.res = res; a.fast_tap = 0;
     a.wide = ((N % E) == 0 && (ldy % E) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
               (!res || ((ldr % E) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0))) ? 1 : 0;
     a.c_shift = 0;

@@ -5,7 +5,7 @@ The reference ships neither the architecture nor the weights (`image-detection/m
 (depth 0.33, width 0.50: 6x6/2 stem, C3 stages 64-128-256-512, SPPF, PAN head, three detect levels at strides 8/16/32,
 anchors of the COCO release) with seeded random weights and `nc` classes (1 in the reference's use: drones).
 Convolutions (channels_last, BatchNorm folded; float32 -- the precision ultralytics' predict runs at -- or float16) run through the
-library's own implicit-GEMM MFMA kernel (`HipConv`, csrc/conv_kernels.hip: conv + bias + SiLU in one launch; exact-f32 or f16
+library's own implicit-GEMM MFMA kernel (`HipConv`, csrc/conv_kernels.hip: conv + bias + SiLU in one launch; float32 -- on the bfloat16 matrix pipes through an exact three-way operand split, or on the float32 matrix instruction -- or f16
 matrix instructions) or, with conv_backend="miopen", through torch / MIOpen; the head decode and the NMS are the hand-written HIP
 kernels of csrc/nms_kernels.hip.  On the HIP path no concatenation is ever materialised: convolutions write channel slices of the
 buffer their consumer reads, and the 1x1 layers behind the head's cat((upsample(a), b)) / cat((conv(x), b)) read both sources."""
@@ -150,7 +150,7 @@ def _nhwc_view(t, b, c, h, w, dtype):
 
 class HipConv(nn.Module):
     """A folded convolution (+ SiLU) through the library's own kernel (csrc/conv_kernels.hip, implicit GEMM on the matrix cores):
-    bf_conv2d_nhwc_f32_* for a float32 convolution (exact f32 products and sums), bf_conv2d_nhwc_f16_* for a float16 one.
+    bf_conv2d_nhwc_f32_* for a float32 convolution (float32 operands, exact products, float32 sums; bf_conv2d_f32_mode picks the matrix instruction), bf_conv2d_nhwc_f16_* for a float16 one.
     In and out: [B, C, H, W] tensors of the convolution's dtype in channels_last memory, i.e. NHWC buffers.
     The weights are repacked once to [N][KH][KW][C'] with C' = the input channels padded to what the kernel takes (the 3-channel
     image of the 6x6 stem becomes 4 channels, the rest are powers of two already), each row zero-padded to whole K stages.
