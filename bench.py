@@ -112,15 +112,20 @@ def cpu_baseline(workload, algo, budget_s=12.0):
     return out
 
 
-def timed(fn, torch, iters, warm=2):
+def timed(fn, torch, iters, warm=2, windows=3):
+    """Seconds per call: the median of `windows` timed runs of `iters` calls each (one run alone is at the mercy of a single allocator or clock hiccup:
+    the extras build and drop several pipelines in one process)."""
     for _ in range(warm):
         fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / iters
+    took = []
+    for _ in range(windows):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        took.append((time.perf_counter() - t0) / iters)
+    return sorted(took)[len(took) // 2]
 
 
 def config_dirs():

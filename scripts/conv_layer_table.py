@@ -24,11 +24,14 @@ ap.add_argument("--size", type=int, default=640)
 ap.add_argument("--half", action="store_true")
 ap.add_argument("--csv", default=None)
 ap.add_argument("--no-miopen", action="store_true")
-ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--f32-mode", choices=["split", "native"], default="split", help="float32 only: bf_conv2d_f32_mode (split = 3 bfloat16 parts per operand, 6 products: the library's default; native = v_mfma_f32_32x32x2_f32)")
 a = ap.parse_args()
 dt = torch.float16 if a.half else torch.float32
 eb = 2 if a.half else 4
-peak = 2500e12 if a.half else 157.3e12
+from lib import _native as nat
+nat.lib.bf_conv2d_f32_mode(1 if a.f32_mode == "split" else 0)
+peak = 2500e12 if a.half else (2500e12 / 6.0 if a.f32_mode == "split" else 157.3e12)       # matrix peak of the instruction mix the mode runs
 HBM = 6.3e12
 
 x3 = torch.rand((a.batch, 3, a.size, a.size), device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
@@ -80,13 +83,19 @@ for m, x, kw in calls:
     nbytes = eb * (x.numel() + (0 if kw["x2"] is None else kw["x2"].numel()) + (0 if kw["residual"] is None else kw["residual"].numel()) + y.numel() + m.n * m.kh * m.kw * m.c)
     for _ in range(2):
         plain(m, x, **kw)
+    # `reps` launches captured into one HIP graph and replayed: a layer of 10-20 us is otherwise timed at the rate Python issues it
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(a.reps):
+            plain(m, x, **kw)
+    graph.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(a.reps):
-        plain(m, x, **kw)
+    graph.replay()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.reps
+    del graph
     floor = max(flop / peak, nbytes / HBM) * 1e3
     rows.append(dict(layer=names[m], cin=m.c, cout=m.n, k=m.kh, stride=m.stride, out_hw="%dx%d" % (ho, wo), sources=1 + (kw["x2"] is not None), up=int(kw["up"]),
                      gflop=flop / 1e9, mbytes=nbytes / 1e6, ms=ms, tflops=flop / ms / 1e9, gbs=nbytes / ms / 1e6, floor_ms=floor,
@@ -104,5 +113,5 @@ if a.csv:
         w.writeheader()
         for r in rows:
             w.writerow({k: ("%.6g" % v if isinstance(v, float) else v) for k, v in r.items()})
-        w.writerow({"layer": "TOTAL batch %d %s" % (a.batch, "f16" if a.half else "f32"), "gflop": "%.6g" % tot_flop, "mbytes": "%.6g" % tot_mb, "ms": "%.6g" % tot_ms,
+        w.writerow({"layer": "TOTAL batch %d %s" % (a.batch, "f16" if a.half else "f32 " + a.f32_mode), "gflop": "%.6g" % tot_flop, "mbytes": "%.6g" % tot_mb, "ms": "%.6g" % tot_ms,
                     "tflops": "%.6g" % (tot_flop / tot_ms), "floor_ms": "%.6g" % tot_floor, "frac": "%.6g" % (tot_floor / tot_ms)})

@@ -12,11 +12,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 ap = argparse.ArgumentParser()
 ap.add_argument("--half", action="store_true")
 ap.add_argument("--tag", default="r03")
+ap.add_argument("--f32-mode", choices=["split", "native"], default="split")
 a = ap.parse_args()
-kind = "f16" if a.half else "f32"
+kind = "f16" if a.half else ("f32" if a.f32_mode == "split" else "f32_native")
 out = os.path.join(ROOT, "gpurun_out", "%s_pmc_conv_%s" % (a.tag, kind))
 cmd = ["rocprofv3", "--kernel-trace", "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE", "-d", out, "-o", "r", "--output-format", "csv", "--",
-       "python3", os.path.join(ROOT, "scripts", "conv_layer_table.py"), "--no-miopen", "--reps", "2"] + (["--half"] if a.half else [])
+       "python3", os.path.join(ROOT, "scripts", "conv_layer_table.py"), "--no-miopen", "--reps", "2", "--f32-mode", a.f32_mode] + (["--half"] if a.half else [])
 rc = subprocess.call(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", timeout=500, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 if rc != 0:
     sys.exit("rocprofv3 failed (%d)" % rc)
@@ -26,11 +27,18 @@ dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for
 agg = {}
 for r in csv.DictReader(open(cc)):
     name = r["Kernel_Name"]
-    m = re.search(r"conv_(dma|igemm)_kernelI(DF16_|f)((?:Li\d+E)+)Lb(\d)", name)          # (float16 instantiations come out mangled)
+    m = re.search(r"conv_(dma|igemm|patch)_kernelI(DF16_|f)((?:Li\d+E)*)(?:Lb(\d)E)?(?:Lb(\d)E)?", name)          # (float16 instantiations come out mangled)
     if m:
-        short = "conv_%s_kernel<%s, %s, %s>" % (m.group(1), "f16" if m.group(2) != "f" else "f32", ", ".join(re.findall(r"Li(\d+)E", m.group(3))), "cat" if m.group(4) == "1" else "plain")
+        short = "conv_%s_kernel<%s>" % (m.group(1), ", ".join(["f16" if m.group(2) != "f" else "f32"] + re.findall(r"Li(\d+)E", m.group(3)) +
+                                                              (["cat" if m.group(4) == "1" else "plain"] if m.group(4) else []) + (["split"] if m.group(5) == "1" else [])))
     elif "bf::" in name and "conv_" in name:
-        short = name[name.index("conv_"):].split("(")[0].replace("float", "f32").replace("true", "cat").replace("false", "plain")
+        short = name[name.index("conv_"):].split("(")[0].replace("float", "f32")
+        t = re.match(r"(conv_\w+)<(.*)>$", short)
+        if t:
+            args = [x.strip() for x in t.group(2).split(",")]
+            bools = [x for x in args if x in ("true", "false")]
+            args = [x for x in args if x not in ("true", "false")] + (["cat" if bools[0] == "true" else "plain"] if bools else []) + (["split"] if len(bools) > 1 and bools[1] == "true" else [])
+            short = "%s<%s>" % (t.group(1), ", ".join(args))
     else:
         continue
     d = agg.setdefault(short, {"n": set(), "ns": 0})
