@@ -214,11 +214,21 @@ def extras(torch, nat, delays, mics, dev):
         # executed matrix flops per bin: covariance 8 M^2 F; quadratic form over the lower-triangular L^-1, whose all-zero 32 x 32 blocks are not issued
         tri = sum(32 * min(M, 32 * (t + 1)) for t in range((M + 31) // 32))
         flop = fb.K * (8.0 * M * M * F + 8.0 * tri * fb.D)
+        how = ("float32 operands; the two bin-reducing GEMMs on 6 x v_mfma_f32_32x32x16_bf16 per 16 values of K (exact 3-way bfloat16 split, float32 sums), "
+               "DFT / covariance on v_mfma_f32_32x32x2_f32") if nat.lib.bf_fd_gemm_f32_mode(-1) == 1 else "v_mfma_f32_32x32x2_f32"
         out["mvdr"] = {"maps_per_s": 1.0 / dt, "frames_per_s": F / dt, "windows_per_map": F, "bins": fb.K, "ms_per_map": dt * 1e3,
-                       "mfma_tflops": flop / dt / 1e12, "mfma_peak_tflops_f32": 157.3,
-                       "flop_note": "executed MFMA flops (dense count of the quadratic form x %.2f: zero blocks of the triangular factor skipped)" % (tri / float(M * M))}
+                       "mfma_tflops": flop / dt / 1e12, "mfma_peak_tflops_f32": 157.3, "matrix_instruction": how,
+                       "flop_note": "executed matrix flops of the float32 products (dense count of the quadratic form x %.2f: zero blocks of the triangular factor skipped)" % (tri / float(M * M))}
         dt = timed(lambda: fb.das_power(frames), torch, 5)
-        out["freq_domain_das"] = {"frames_per_s": F / dt, "ms_per_step": dt * 1e3, "mfma_tflops": fb.K * 8.0 * M * F * fb.D / dt / 1e12}
+        out["freq_domain_das"] = {"frames_per_s": F / dt, "ms_per_step": dt * 1e3, "mfma_tflops": fb.K * 8.0 * M * F * fb.D / dt / 1e12, "matrix_instruction": how}
+        initial = nat.lib.bf_fd_gemm_f32_mode(0)               # the same two on the float32 matrix instruction, for comparison
+        try:
+            dt = timed(lambda: fb.mvdr_power(frames, 1e-2), torch, 5)
+            out["mvdr_f32_mfma_instruction"] = {"maps_per_s": 1.0 / dt, "ms_per_map": dt * 1e3, "mfma_tflops": flop / dt / 1e12, "mfma_peak_tflops_f32": 157.3}
+            dt = timed(lambda: fb.das_power(frames), torch, 5)
+            out["freq_domain_das_f32_mfma_instruction"] = {"frames_per_s": F / dt, "ms_per_step": dt * 1e3, "mfma_tflops": fb.K * 8.0 * M * F * fb.D / dt / 1e12}
+        finally:
+            nat.lib.bf_fd_gemm_f32_mode(initial)
         # BASELINE config 5's array: 4 tiles = 256 mics (two-block Cholesky), the as-shipped 57 x 32 grid, 320 windows per map
         C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y = 256, 4, 57, 32
         fb4 = B.FrequencyBeamformer()

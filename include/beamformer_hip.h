@@ -207,7 +207,12 @@ int bf_power_center_device(const float *d_power, int frames, float *d_centers, f
  *                           d_status int32 [K] (zeroed by the caller) receives j+1 where a pivot was not positive
  *   bf_fd_mvdr_power_device P[d] = sum_k 1 / || inverse(L_k) a[k][:, d] ||^2                                     -> float32 [D]
  *                           d_lire_t / d_liim_t are the planes bf_fd_cholesky_inverse_device writes, [K][col][row] of a LOWER-TRIANGULAR inverse: entries with
- *                           col > row are taken to be zero and whole 32 x 32 blocks of them are not multiplied at all  */
+ *                           col > row are taken to be zero and whole 32 x 32 blocks of them are not multiplied at all
+ *   bf_fd_gemm_f32_mode     how the two bin-reducing GEMMs (bf_fd_das_power_device, bf_fd_mvdr_power_device) multiply: 0 = v_mfma_f32_32x32x2_f32,
+ *                           1 = exact three-way bfloat16 split of the float32 operands, six part products per product on v_mfma_f32_32x32x16_bf16,
+ *                           float32 accumulation (float32 accuracy: tests/test_freqdomain.py holds both modes to the same bounds).  mode < 0 only
+ *                           asks; returns the previous setting ($BF_GEMM_F32=native|split sets the initial one)  */
+int bf_fd_gemm_f32_mode(int mode);
 int bf_fd_steering_device(const double *d_tau, const double *d_freq, int n_dirs, int n_mics, int n_bins, float *d_are, float *d_aim, void *stream);
 int bf_fd_dft_device(const float *d_frames, int m_total, int frames, const int *adaptive_array, int n, int bin_lo, int n_bins,
                      float *d_xre_mf, float *d_xim_mf, float *d_xre_fm, float *d_xim_fm, void *stream);

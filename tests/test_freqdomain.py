@@ -193,9 +193,17 @@ GEMM_SHAPES = [
 ]
 
 
+@pytest.fixture(params=[0, 1], ids=["f32_mfma", "bf16_split"])
+def gemm_mode(request, native):
+    """bf_fd_gemm_f32_mode for the test: the float32 matrix instruction, and the exact three-way bfloat16 split (same bounds for both)."""
+    initial = native.lib.bf_fd_gemm_f32_mode(request.param)
+    yield request.param
+    native.lib.bf_fd_gemm_f32_mode(initial)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("I,K,J,B", GEMM_SHAPES)
-def test_gpu_bin_reducing_gemms_match_numpy(native, I, K, J, B):
+def test_gpu_bin_reducing_gemms_match_numpy(native, gemm_mode, I, K, J, B):
     """bf_fd_das_power_device / bf_fd_mvdr_power_device on random complex operands against complex128 NumPy:
     P[f, d] = sum_b |sum_k X[b,k,f] A[b,k,d]|^2   and   P[d] = sum_b 1 / sum_i |sum_k L[b,k,i] conj(A[b,k,d])|^2."""
     import torch
@@ -213,7 +221,7 @@ def test_gpu_bin_reducing_gemms_match_numpy(native, I, K, J, B):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,J,B", [(37, 45, 9), (64, 333, 23), (100, 70, 4), (128, 200, 6)])
-def test_gpu_mvdr_quadratic_form_matches_numpy(native, M, J, B):
+def test_gpu_mvdr_quadratic_form_matches_numpy(native, gemm_mode, M, J, B):
     """bf_fd_mvdr_power_device on a random (transposed) triangular-inverse stand-in L[b, k, i] = Linv[i][k], zero for k > i as the planes of
     bf_fd_cholesky_inverse_device are (the kernel does not multiply the all-zero 32 x 32 blocks):
     P[d] = sum_b 1 / sum_i |sum_k L[b,k,i] conj(A[b,k,d])|^2  against complex128 NumPy."""

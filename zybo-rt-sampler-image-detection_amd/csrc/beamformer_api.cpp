@@ -1238,6 +1238,7 @@ int bf_preprocess_bgr8_f32_device(const void* d_frames, void* d_out, int batch, 
 
 int bf_conv2d_use_dma_kernel(int enable) { return bf::conv_dma_switch(enable); }
 int bf_conv2d_f32_mode(int mode) { return bf::conv_f32_mode(mode); }
+int bf_fd_gemm_f32_mode(int mode) { return bf::gemm_f32_mode(mode); }
 
 int bf_conv2d_weight_row(int kh, int kw, int c) { return kh > 0 && kw > 0 && c > 0 ? bf::conv_weight_row(2, kh, kw, c) : -1; }
 int bf_conv2d_weight_row_f32(int kh, int kw, int c) { return kh > 0 && kw > 0 && c > 0 ? bf::conv_weight_row(4, kh, kw, c) : -1; }

@@ -147,6 +147,7 @@ hipError_t launch_preprocess_bgr8(const void* frames, void* out, long long pixel
 // concatenation (x [.., c1) at pixel pitch ld1, optionally 2x-upsampled; x2 [c1, C) at pitch ld2) -- pass nullptr, C, C, 0, 0 otherwise.
 int conv_dma_switch(int value);
 int conv_f32_mode(int value);
+int gemm_f32_mode(int value);
 int conv_weight_row(int elem_bytes, int kh, int kw, int c);
 hipError_t launch_conv2d_nhwc(int elem_bytes, const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C, int N, int KH, int KW,
                               int stride, int pad, int act, int ldy, const void* res, int ldr, const void* x2, int c1, int ld1, int ld2, int up1,

@@ -19,8 +19,26 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <stdint.h>
+#include <cstdlib>
+#include <cstring>
+
+#include "f32_split.h"
 
 namespace bf {
+
+// How the bin-reducing float32 GEMMs (phase-steer power map, MVDR quadratic form) multiply: 0 = v_mfma_f32_32x32x2_f32 on the operands as they are,
+// 1 = three-way bfloat16 split of both operands and six v_mfma_f32_32x32x16_bf16 per product (f32_split.h: float32 accuracy, 2.67 x the matrix rate).
+// $BF_GEMM_F32=native|split sets the initial mode; value < 0 only reads.  Returns the previous setting.
+#ifndef BF_GEMM_F32_DEFAULT
+#define BF_GEMM_F32_DEFAULT 1
+#endif
+int gemm_f32_mode(int value)
+{
+    static int state = [] { const char* e = getenv("BF_GEMM_F32"); return e ? (strcmp(e, "split") == 0 ? 1 : 0) : BF_GEMM_F32_DEFAULT; }();
+    const int old = state;
+    if (value >= 0) state = value != 0 ? 1 : 0;
+    return old;
+}
 
 namespace {
 
@@ -170,10 +188,15 @@ __device__ __forceinline__ void load_panel(Panel& p, const float* __restrict__ r
     }
 }
 
-template <int EPI, int RT>
+// SPLIT: the same products on the bfloat16 pipes (f32_split.h).  The panels' register order is already what v_mfma_f32_32x32x16_bf16 wants: a lane's
+// registers [8 t, 8 t + 8) are its eight values of K step t (k = k0 + 16 t + 2 i + (lane >> 5)), for A and B alike.  A bin's B panel is split once
+// (24 registers per K step instead of 16), an A panel's step right before its 24 MFMAs (4 real products x 6 part products; -Ai Bi by flipping the
+// sign bits of Ai's parts in place after Ai Br has been issued).
+template <int EPI, int RT, bool SPLIT>
 __global__ void __launch_bounds__(256, 2) cgemm_bins_kernel(GemmArgs g, int row_groups, int bins_per_group)
 {
     static_assert(EPI == EPI_POWER || EPI == EPI_MVDR, "bin-reducing epilogues");
+    using split::Split3;
     extern __shared__ float red[];              // [4 waves][RT * 16][64 lanes] (POWER) or [4][32] (MVDR)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -200,7 +223,20 @@ __global__ void __launch_bounds__(256, 2) cgemm_bins_kernel(GemmArgs g, int row_
         const float* are = g.a_re + ((size_t)b * g.K) * g.I;
         const float* aim = g.a_im + ((size_t)b * g.K) * g.I;
         Panel Bp;
-        if (single) load_panel(Bp, bre, bim, g.J, 0, g.K, lk, b_voff, bj_ok, g.conj_b != 0);
+        Split3 Bs_re[SPLIT ? 4 : 1], Bs_im[SPLIT ? 4 : 1];
+        auto split_b = [&]() {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                Bs_re[t] = split::split3(split::float4v{Bp.re[8 * t], Bp.re[8 * t + 1], Bp.re[8 * t + 2], Bp.re[8 * t + 3]},
+                                         split::float4v{Bp.re[8 * t + 4], Bp.re[8 * t + 5], Bp.re[8 * t + 6], Bp.re[8 * t + 7]});
+                Bs_im[t] = split::split3(split::float4v{Bp.im[8 * t], Bp.im[8 * t + 1], Bp.im[8 * t + 2], Bp.im[8 * t + 3]},
+                                         split::float4v{Bp.im[8 * t + 4], Bp.im[8 * t + 5], Bp.im[8 * t + 6], Bp.im[8 * t + 7]});
+            }
+        };
+        if (single) {
+            load_panel(Bp, bre, bim, g.J, 0, g.K, lk, b_voff, bj_ok, g.conj_b != 0);
+            if constexpr (SPLIT) split_b();
+        }
         float colsum = 0.0f;
 
         auto row_tile = [&](int rt, f32x16* accp) {
@@ -213,6 +249,49 @@ __global__ void __launch_bounds__(256, 2) cgemm_bins_kernel(GemmArgs g, int row_
             // MVDR: the A operand is L^-1 (transposed planes), lower triangular -- rows [ib, ib + 32) meet columns k < ib + 32 only, so the k-steps
             // beyond are products with zeros and are not issued (64 microphones: 192 instead of 256 MFMAs per bin and column tile).
             const int kmax = (EPI == EPI_MVDR) ? min(g.K, ib + 32) : g.K;
+            if constexpr (SPLIT) {
+                // the A operand arrives one 16-deep K step at a time (8 + 8 registers), the next step's loads in flight under this step's 24 MFMAs:
+                // with the bin's split B panel resident (96 registers) a whole 64-deep A panel would not fit beside the accumulators
+                auto load_a = [&](float (&re8)[8], float (&im8)[8], int kb) {
+                    const bool whole = kb + 16 <= g.K;                                   // (uniform)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int k = kb + 2 * i;
+                        const size_t row = (size_t)k * (size_t)g.I;
+                        const bool ok = a_ok && (whole || k + lk < g.K);
+                        re8[i] = ok ? (are + row)[a_voff] : 0.0f;
+                        im8[i] = ok ? (aim + row)[a_voff] : 0.0f;
+                    }
+                };
+                auto step = [&](const float (&re8)[8], const float (&im8)[8], const Split3& br, const Split3& bi) {
+                    const Split3 ar = split::split3(split::float4v{re8[0], re8[1], re8[2], re8[3]}, split::float4v{re8[4], re8[5], re8[6], re8[7]});
+                    Split3 ai = split::split3(split::float4v{im8[0], im8[1], im8[2], im8[3]}, split::float4v{im8[4], im8[5], im8[6], im8[7]});
+                    split::mfma6(cre, ar, br);
+                    split::mfma6(cim, ar, bi);
+                    split::mfma6(cim, ai, br);
+                    split::negate(ai);
+                    split::mfma6(cre, ai, bi);
+                };
+                float r0[8], i0[8], r1[8], i1[8];
+                for (int k0 = 0; k0 < kmax; k0 += 64) {
+                    if (!single) {
+                        load_panel(Bp, bre, bim, g.J, k0, g.K, lk, b_voff, bj_ok, g.conj_b != 0);
+                        split_b();
+                    }
+                    load_a(r0, i0, k0);
+                    if (k0 + 16 < kmax) load_a(r1, i1, k0 + 16);
+                    step(r0, i0, Bs_re[0], Bs_im[0]);
+                    if (k0 + 16 < kmax) {                                               // (uniform)
+                        if (k0 + 32 < kmax) load_a(r0, i0, k0 + 32);
+                        step(r1, i1, Bs_re[1], Bs_im[1]);
+                        if (k0 + 32 < kmax) {
+                            if (k0 + 48 < kmax) load_a(r1, i1, k0 + 48);
+                            step(r0, i0, Bs_re[2], Bs_im[2]);
+                            if (k0 + 48 < kmax) step(r1, i1, Bs_re[3], Bs_im[3]);
+                        }
+                    }
+                }
+            } else
             for (int k0 = 0; k0 < kmax; k0 += 64) {
                 const bool both = k0 + 32 < kmax;              // (uniform) the panel's second half is needed
                 Panel Ap;
@@ -810,8 +889,8 @@ int bin_groups(int col_tiles, int row_groups, int n_bins)
     return want < 1 ? 1 : want;
 }
 
-template <int EPI, int RT>
-hipError_t run_bins(const GemmArgs& g0, int row_groups, float* d_work, size_t work_floats, size_t plane, hipStream_t stream)
+template <int EPI, int RT, bool SPLIT>
+hipError_t run_bins_t(const GemmArgs& g0, int row_groups, float* d_work, size_t work_floats, size_t plane, hipStream_t stream)
 {
     GemmArgs g = g0;
     const int col_tiles = (g.J + 31) / 32;
@@ -822,7 +901,7 @@ hipError_t run_bins(const GemmArgs& g0, int row_groups, float* d_work, size_t wo
     float* final_out = g.out0;
     if (groups > 1) g.out0 = d_work;
     const size_t lds = (EPI == EPI_POWER) ? (size_t)4 * RT * 16 * 64 * sizeof(float) : (size_t)4 * 32 * sizeof(float);
-    auto kernel = cgemm_bins_kernel<EPI, RT>;
+    auto kernel = cgemm_bins_kernel<EPI, RT, SPLIT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3((unsigned)(col_tiles * row_groups), (unsigned)groups), dim3(256), lds, stream, g, row_groups, per_group);
@@ -830,6 +909,13 @@ hipError_t run_bins(const GemmArgs& g0, int row_groups, float* d_work, size_t wo
     if (e != hipSuccess || groups == 1) return e;
     hipLaunchKernelGGL(reduce_planes_kernel, dim3(1024), dim3(256), 0, stream, d_work, groups, plane, final_out);
     return hipGetLastError();
+}
+
+template <int EPI, int RT>
+hipError_t run_bins(const GemmArgs& g, int row_groups, float* d_work, size_t work_floats, size_t plane, hipStream_t stream)
+{
+    return gemm_f32_mode(-1) == 1 ? run_bins_t<EPI, RT, true>(g, row_groups, d_work, work_floats, plane, stream)
+                                  : run_bins_t<EPI, RT, false>(g, row_groups, d_work, work_floats, plane, stream);
 }
 
 }  // namespace

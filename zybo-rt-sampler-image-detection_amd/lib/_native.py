@@ -118,6 +118,7 @@ _sig("bf_conv2d_nhwc_f16_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C
 _sig("bf_letterbox_bgr8_device", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p)
 _sig("bf_conv2d_use_dma_kernel", C.c_int, C.c_int)
 _sig("bf_conv2d_f32_mode", C.c_int, C.c_int)
+_sig("bf_fd_gemm_f32_mode", C.c_int, C.c_int)
 _sig("bf_conv2d_weight_row_f32", C.c_int, C.c_int, C.c_int, C.c_int)
 _sig("bf_conv2d_nhwc_f32_into_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p)
 _sig("bf_conv2d_nhwc_f32_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p)
