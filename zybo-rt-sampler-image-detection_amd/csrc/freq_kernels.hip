@@ -931,8 +931,12 @@ hipError_t launch_fd_das_power(const float* xre_mf, const float* xim_mf, const f
 {
     GemmArgs g{xre_mf, xim_mf, are, aim, d_power, nullptr, n_frames, n_dirs, n_mics, n_bins, 0, 1.0f};
     // row tiles (32 frames each) per wave: at most 4 (its |C|^2 accumulators live in registers), balanced over the row groups
+    // ($BF_FD_RT caps it for A/B runs; split mode, config 3: 1 / 2 / 3 / 4 -> 1.15 / 1.05 / 1.04 / 1.05 ms -- the few spilled registers of the 3- and 4-tile
+    //  instantiations cost less than a bin's B panel split once more)
+    static const int rt_env = [] { const char* e = getenv("BF_FD_RT"); return e ? atoi(e) : 0; }();
+    const int rt_max = rt_env >= 1 && rt_env <= 4 ? rt_env : 4;
     const int tiles = (n_frames + 31) / 32;
-    const int row_groups = (tiles + 3) / 4;
+    const int row_groups = (tiles + rt_max - 1) / rt_max;
     const int rt = (tiles + row_groups - 1) / row_groups;
     const size_t plane = (size_t)n_frames * n_dirs;
     switch (rt) {
