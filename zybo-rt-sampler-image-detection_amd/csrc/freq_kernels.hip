@@ -845,6 +845,122 @@ hipError_t launch_fd_twiddles(int n_samples, int bin_lo, int n_bins, float* d_tw
     return hipGetLastError();
 }
 
+namespace {
+
+// The same DFT with a finer split: a workgroup owns 32 rows (= 32 consecutive (frame, mic) pairs), its waves one 32-bin tile each.  A 64-sample chunk of the
+// 32 signal rows is staged through LDS by coalesced loads (dft_mfma_kernel's lanes fetched their operand sample by sample from rows 1 KiB apart), three times as
+// many workgroups fill the chip (config 3: 380 instead of 95), and only the [K][F][M] layout is written here -- rows are consecutive addresses of it --, the
+// [K][M][F] one by transpose_planes_kernel (dft_mfma_kernel scattered it in 4-byte stores).
+template <int KT>
+__global__ void __launch_bounds__(256) dft_tile_kernel(const float* __restrict__ frames, const int32_t* __restrict__ mics, int m_total, int n_samples,
+                                                       int n_frames, int n_mics, int n_bins, int kp_total, const float* __restrict__ wc,
+                                                       const float* __restrict__ ws, float* __restrict__ xre_fm, float* __restrict__ xim_fm)
+{
+    constexpr int KP = 32 * KT, SP = 65;
+    const int kofs = blockIdx.y * KP;
+    __shared__ float sig[2][32 * SP];           // the signal rows' current 64-sample chunk, double-buffered
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const long long rows = (long long)n_frames * n_mics;
+    const long long r0 = (long long)blockIdx.x * 32;
+    // staging role: thread t fills samples [8 (t & 7), +8) of row t >> 3 of the chunk
+    const long long sr = r0 + (tid >> 3);
+    const bool s_ok = sr < rows;
+    const int sf = s_ok ? (int)(sr / n_mics) : 0, sm = s_ok ? (int)(sr - (long long)sf * n_mics) : 0;
+    const float* srow = frames + ((size_t)sf * m_total + (s_ok ? mics[sm] : 0)) * n_samples;
+    float nx[8];                                 // the next chunk's samples on their way: requested before a chunk's MFMAs, stored to LDS after them
+    auto fetch = [&](int n0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = n0 + (tid & 7) * 8 + j;
+            nx[j] = (s_ok && n < n_samples) ? srow[n] : 0.0f;
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sig[buf][(tid >> 3) * SP + (tid & 7) * 8 + j] = nx[j];
+    };
+    // this wave's twiddle operands come straight from the table (rows of kp_total bins, 32 consecutive bins per half wave: one 128-byte line; the table
+    // stays in L2), no staging
+    const int kb = kofs + 32 * wave + li;
+    const bool k_ok = wave < KT && kb < kp_total;
+    const float* wcp = wc + (k_ok ? kb : 0);
+    const float* wsp = ws + (k_ok ? kb : 0);
+    f32x16 are_, aim_;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { are_[q] = 0.0f; aim_[q] = 0.0f; }
+    // Every workgroup walks the whole table; started together at sample 0 they would all ask one L2 channel for the same lines at the same time (measured:
+    // 63 us for config 3, the table's traffic through one channel at a time).  Each workgroup therefore starts at its own chunk and its own place inside the
+    // chunk -- a sum over the same terms in a rotated order.
+    const int n_chunks = (n_samples + 63) / 64;
+    const int c_first = (int)(blockIdx.x % (unsigned)n_chunks), s_first = (int)((blockIdx.x / (unsigned)n_chunks) & 3u) * 8;
+    fetch(c_first * 64);
+    store(0);
+    int buf = 0;
+    for (int ci = 0; ci < n_chunks; ++ci, buf ^= 1) {
+        const int cc = ci + c_first, n0 = (cc >= n_chunks ? cc - n_chunks : cc) * 64;
+        __syncthreads();                                          // chunk n0 is in sig[buf]; sig[buf ^ 1]'s readers are done
+        const bool more = ci + 1 < n_chunks;
+        if (more) fetch((cc + 1 >= n_chunks ? cc + 1 - n_chunks : cc + 1) * 64);
+        if (wave < KT) {
+#pragma unroll 8
+            for (int si = 0; si < 32; ++si) {
+                const int s2 = (si + s_first) & 31;
+                // (unconditional loads: a sample past the last has a zero in `sig`, a bin past the table's last is never stored -- a conditional load
+                //  is a branch around it, and 64 of those per chunk serialise the loop)
+                const int n = min(n0 + 2 * s2 + lk, n_samples - 1);
+                const float b = sig[buf][li * SP + 2 * s2 + lk];
+                const float c = wcp[(size_t)n * kp_total];
+                const float sn = wsp[(size_t)n * kp_total];
+                are_ = __builtin_amdgcn_mfma_f32_32x32x2f32(c, b, are_, 0, 0, 0);
+                aim_ = __builtin_amdgcn_mfma_f32_32x32x2f32(sn, b, aim_, 0, 0, 0);
+            }
+        }
+        if (more) store(buf ^ 1);
+    }
+    const long long r = r0 + li;
+    if (wave >= KT || r >= rows) return;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int k = kofs + 32 * wave + acc_row(q, lane);
+        if (k < n_bins) {
+            const size_t fm = (size_t)k * (size_t)rows + (size_t)r;                  // ((k F + f) M + m)
+            xre_fm[fm] = are_[q];
+            xim_fm[fm] = aim_[q];
+        }
+    }
+}
+
+// [K][F][M] -> [K][M][F], both planes: 32 x 32 tiles through LDS
+__global__ void __launch_bounds__(256) transpose_planes_kernel(const float* __restrict__ in_re, const float* __restrict__ in_im, float* __restrict__ out_re,
+                                                               float* __restrict__ out_im, int F, int M)
+{
+    __shared__ float tr[32][33], ti[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int k = blockIdx.z, m0 = blockIdx.x * 32, f0 = blockIdx.y * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = f0 + ty + 8 * j, m = m0 + tx;
+        if (f < F && m < M) {
+            const size_t at = ((size_t)k * F + f) * M + m;
+            tr[ty + 8 * j][tx] = in_re[at];
+            ti[ty + 8 * j][tx] = in_im[at];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + ty + 8 * j, f = f0 + tx;
+        if (m < M && f < F) {
+            const size_t at = ((size_t)k * M + m) * F + f;
+            out_re[at] = tr[tx][ty + 8 * j];
+            out_im[at] = ti[tx][ty + 8 * j];
+        }
+    }
+}
+
+}  // namespace
+
 hipError_t launch_fd_dft(const float* d_frames, const int32_t* d_mics, int m_total, int n_samples, int n_frames, int n_mics, int bin_lo, int n_bins,
                          const float* d_tw, float* xre_mf, float* xim_mf, float* xre_fm, float* xim_fm, hipStream_t stream)
 {
@@ -861,6 +977,27 @@ hipError_t launch_fd_dft(const float* d_frames, const int32_t* d_mics, int m_tot
     const float* wc = d_tw;
     const float* ws = d_tw + (size_t)n_samples * kp;
     const long long rows = (long long)n_frames * n_mics;
+    static const int tile_env = [] { const char* e = getenv("BF_FD_DFT_TILE"); return e ? atoi(e) : 1; }();      // 0: dft_mfma_kernel (A/B)
+    if (tile_env != 0) {
+        const dim3 grid32((unsigned)((rows + 31) / 32), (unsigned)groups);
+        const size_t lds32 = 0;
+        auto go32 = [&](auto kernel) -> hipError_t {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kernel, grid32, dim3(256), lds32, stream, d_frames, d_mics, m_total, n_samples, n_frames, n_mics, n_bins, kp, wc, ws, xre_fm, xim_fm);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(transpose_planes_kernel, dim3((unsigned)((n_mics + 31) / 32), (unsigned)((n_frames + 31) / 32), (unsigned)n_bins), dim3(256), 0, stream,
+                               xre_fm, xim_fm, xre_mf, xim_mf, n_frames, n_mics);
+            return hipGetLastError();
+        };
+        switch (kt) {
+            case 1: return go32(dft_tile_kernel<1>);
+            case 2: return go32(dft_tile_kernel<2>);
+            case 3: return go32(dft_tile_kernel<3>);
+            default: return go32(dft_tile_kernel<4>);
+        }
+    }
     const dim3 grid((unsigned)((rows + 127) / 128), (unsigned)groups);
     const size_t lds = (size_t)2 * 64 * (32 * kt) * sizeof(float);
     auto go = [&](auto kernel) -> hipError_t {
