@@ -267,7 +267,9 @@ int bf_conv2d_use_dma_kernel(int enable);
 /*   bf_conv2d_f32_mode: how the float32 LDS-DMA convolution kernels multiply.  0 = the float32 matrix instruction on the operands as they are
  *       (v_mfma_f32_32x32x2_f32); 1 = every operand value split exactly into three bfloat16 parts and the product accumulated (in float32) from the
  *       six part products that matter (v_mfma_f32_32x32x16_bf16): float32 accuracy -- measured against float64 in tests/test_detector.py -- at
- *       2.67 x the matrix rate.  mode < 0 only asks; returns the previous setting ($BF_CONV_F32=native|split sets the initial one). */
+ *       2.67 x the matrix rate.  Differences from the float32 instruction: the summation order, an infinite operand gives NaN (inf - inf in the split)
+ *       where the instruction gives an infinity, and operands below 2^-118 lose their low parts to bfloat16's exponent range (float32's own
+ *       subnormal neighbourhood).  mode < 0 only asks; returns the previous setting ($BF_CONV_F32=native|split sets the initial one). */
 int bf_conv2d_f32_mode(int mode);
 int bf_conv2d_nhwc_f16_device(const void *d_x, const void *d_w, const float *d_bias, void *d_y, int batch, int h, int w, int c, int n, int kh, int kw,
                               int stride, int pad, int silu, void *stream);

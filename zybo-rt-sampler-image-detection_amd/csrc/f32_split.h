@@ -6,6 +6,8 @@
 // of the float32 rounding of the sum itself).  Accumulation is the MFMA's float32.  Six v_mfma_f32_32x32x16_bf16 of 32 cycles replace eight
 // v_mfma_f32_32x32x2_f32 of 64 cycles for the same 16 values of K: 2.67 x the matrix rate; the price is 5.5 vector instructions per operand value.
 // Measured against float64 (tests/test_detector.py, tests/test_freqdomain.py) the error is at or below the float32 instruction's.
+// Not the same as the instruction at the edges of the format: an infinite x gives NaN parts (x - h = inf - inf), and below |x| = 2^-118 the parts m and l
+// fall under bfloat16's smallest normal number (it shares float32's exponent range) and may be flushed -- relative error up to 2^-8 on values that small.
 #pragma once
 #include <hip/hip_runtime.h>
 
