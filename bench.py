@@ -211,12 +211,15 @@ def extras(torch, nat, delays, mics, dev):
         F = 190
         frames = torch.from_numpy(synth.frame_batch(M, N, 64)).to(dev).repeat(3, 1, 1)[:F].contiguous()
         dt = timed(lambda: fb.mvdr_power(frames, 1e-2), torch, 5)
+        dt_stream = timed(lambda: fb.mvdr_power(frames, 1e-2, defer_check=True), torch, 5)     # the same maps without a host read-back per map
+        fb.check_deferred()
         # executed matrix flops per bin: covariance 8 M^2 F; quadratic form over the lower-triangular L^-1, whose all-zero 32 x 32 blocks are not issued
         tri = sum(32 * min(M, 32 * (t + 1)) for t in range((M + 31) // 32))
         flop = fb.K * (8.0 * M * M * F + 8.0 * tri * fb.D)
         how = ("float32 operands; the two bin-reducing GEMMs on 6 x v_mfma_f32_32x32x16_bf16 per 16 values of K (exact 3-way bfloat16 split, float32 sums), "
                "DFT / covariance on v_mfma_f32_32x32x2_f32") if nat.lib.bf_fd_gemm_f32_mode(-1) == 1 else "v_mfma_f32_32x32x2_f32"
         out["mvdr"] = {"maps_per_s": 1.0 / dt, "frames_per_s": F / dt, "windows_per_map": F, "bins": fb.K, "ms_per_map": dt * 1e3,
+                       "maps_per_s_streamed": 1.0 / dt_stream, "streamed_note": "status of the factorisations checked once after the run (defer_check) instead of read back per map",
                        "mfma_tflops": flop / dt / 1e12, "mfma_peak_tflops_f32": 157.3, "matrix_instruction": how,
                        "flop_note": "executed matrix flops of the float32 products (dense count of the quadratic form x %.2f: zero blocks of the triangular factor skipped)" % (tri / float(M * M))}
         dt = timed(lambda: fb.das_power(frames), torch, 5)

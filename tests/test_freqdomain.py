@@ -344,3 +344,31 @@ def test_gpu_direction_shards_of_the_frequency_domain_maps(native):
         assert torch.allclose(one[0], want_mvdr, rtol=1e-6, atol=0)
     finally:
         C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y = old
+
+
+@pytest.mark.gpu
+def test_gpu_mvdr_deferred_status_check(native):
+    """mvdr_power(defer_check=True) returns the same map without the per-map read-back, and check_deferred() raises what the immediate check raises:
+    a covariance made indefinite (negative loading on rank-deficient data) is reported by both."""
+    import torch
+    from realtime_scripts import beam_forming_algorithm as B, config as C
+    old = (C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y)
+    C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y = 64, 1, 11, 11
+    try:
+        fb = B.FrequencyBeamformer()
+        rng = np.random.default_rng(5)
+        frames = torch.from_numpy(rng.standard_normal((96, 64, C.N_SAMPLES)).astype(np.float32)).cuda()
+        now = fb.mvdr_power(frames, 1e-2)
+        later = fb.mvdr_power(frames, 1e-2, defer_check=True)
+        fb.check_deferred()
+        assert torch.equal(now, later)
+        few = frames[:8].contiguous()                       # 8 windows, 64 mics: rank 8, and a negative loading makes it indefinite
+        with pytest.raises(Exception):
+            fb.mvdr_power(few, -1e-3)
+        fb.mvdr_power(few, -1e-3, defer_check=True)
+        fb.mvdr_power(frames, 1e-2, defer_check=True)       # a good map after the bad one does not clear the report
+        with pytest.raises(Exception):
+            fb.check_deferred()
+        fb.check_deferred()                                 # cleared
+    finally:
+        C.N_MICROPHONES, C.ACTIVE_ARRAYS, C.MAX_RES_X, C.MAX_RES_Y = old

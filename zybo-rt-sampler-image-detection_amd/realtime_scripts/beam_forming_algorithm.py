@@ -120,8 +120,11 @@ class FrequencyBeamformer:
         mx = p.amax(dim=1, keepdim=True)
         return self.torch.where(mx < threshold_heatmap, self.torch.zeros_like(p), p / mx)
 
-    def mvdr_power(self, d_frames, loading=1e-2):
-        """One MVDR (Capon) map from F windows of the same scene: float32 [MAX_RES_X*MAX_RES_Y].  Not in the reference."""
+    def mvdr_power(self, d_frames, loading=1e-2, defer_check=False):
+        """One MVDR (Capon) map from F windows of the same scene: float32 [MAX_RES_X*MAX_RES_Y].  Not in the reference.
+        The factorisation reports bins whose covariance is not positive definite; reading that report back is a host synchronisation per map.
+        `defer_check=True` folds it into a device-side running maximum instead (one tiny kernel) and returns at once: a stream of maps then
+        pipelines, and `check_deferred()` -- to be called before the maps are trusted -- raises what the immediate check would have raised."""
         t = self.torch
         x = self.spectra(d_frames)
         mk = lambda *s: t.empty(s, dtype=t.float32, device=self.device)
@@ -133,9 +136,19 @@ class FrequencyBeamformer:
                    l_im.data_ptr(), status.data_ptr())
         self._call(nat.lib.bf_fd_mvdr_power_device, l_re.data_ptr(), l_im.data_ptr(), self.a_re.data_ptr(), self.a_im.data_ptr(), self.M, self.D, self.K,
                    p.data_ptr())
+        if defer_check:
+            worst = getattr(self, "_deferred_status", None)
+            self._deferred_status = status if worst is None else t.maximum(worst, status)
+            return p
         if int(status.max().item()) != 0:
             raise nat.BeamformerError("MVDR covariance is not positive definite in %d bin(s); raise `loading`" % int((status != 0).sum().item()))
         return p
+
+    def check_deferred(self):
+        """The positive-definiteness report of every `mvdr_power(..., defer_check=True)` call since the last check (synchronises)."""
+        worst, self._deferred_status = getattr(self, "_deferred_status", None), None
+        if worst is not None and int(worst.max().item()) != 0:
+            raise nat.BeamformerError("MVDR covariance was not positive definite in %d bin(s) of at least one map; raise `loading`" % int((worst != 0).sum().item()))
 
 
 _default = None
