@@ -91,22 +91,24 @@ def test_gpu_reference_named_functions(native):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,h,with_cam", [(640, 640, False), (322, 200, True), (322, 200, False), (1280, 720, True), (4, 3, True)])
-def test_gpu_overlay_both_kernels(native, w, h, with_cam):
-    """bf_heatmap_overlay_device picks the four-pixel kernel when the width allows it and the one-pixel kernel otherwise: both equal the
-    oracle's resize + blend chain byte for byte, with and without a camera frame, over three frames of a carried `prev`."""
+@pytest.mark.parametrize("w,h,with_cam,n_frames", [(640, 640, False, 3), (322, 200, True, 3), (322, 200, False, 3), (1280, 720, True, 3), (4, 3, True, 3),
+                                                   (256, 128, True, 60), (640, 640, True, 11)])
+def test_gpu_overlay_both_kernels(native, w, h, with_cam, n_frames):
+    """bf_heatmap_overlay_device picks the tiled kernel when the width allows it and the one-pixel kernel otherwise: both equal the
+    oracle's resize + blend chain byte for byte, with and without a camera frame, over the frames of a batch with a carried `prev`
+    (60 frames at 256 x 128: the tile's source pixels of all frames do not fit LDS at once -- three chunks; 11 frames: a ragged group of eight)."""
     import torch
     import visual
     import visual_np as V
     c = util.configure("cfg2")
     rng = np.random.default_rng(w * 7 + h)
-    small = rng.integers(0, 256, (3, c["Y"], c["X"], 3), dtype=np.uint8)
-    cam = rng.integers(0, 256, (3, h, w, 3), dtype=np.uint8)
+    small = rng.integers(0, 256, (n_frames, c["Y"], c["X"], 3), dtype=np.uint8)
+    cam = rng.integers(0, 256, (n_frames, h, w, 3), dtype=np.uint8)
     st = visual.HeatmapStream(w, h)
     st.prev.copy_(torch.from_numpy(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)))
     prev = st.prev.cpu().numpy()
     out = st.overlay(torch.from_numpy(small).cuda(), torch.from_numpy(cam).cuda() if with_cam else None, 0.4, 0.7, 0.9, 0.8).cpu().numpy()
-    for f in range(3):
+    for f in range(n_frames):
         prev = V.add_weighted_u8(prev, 0.4, V.resize_linear_u8(small[f], w, h), 0.7)
         assert np.array_equal(out[f], V.add_weighted_u8(cam[f], 0.9, prev, 0.8) if with_cam else prev)
     assert np.array_equal(st.prev.cpu().numpy(), prev)
