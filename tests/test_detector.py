@@ -630,9 +630,10 @@ def test_gpu_preprocess_kernel_matches_torch(native, half):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("half", [True, False])
-@pytest.mark.parametrize("B,C,H,W", [(2, 256, 20, 20), (1, 64, 12, 20), (3, 8, 5, 3)])
+@pytest.mark.parametrize("B,C,H,W", [(2, 256, 20, 20), (1, 64, 12, 20), (3, 8, 5, 3), (1, 64, 40, 40), (2, 24, 9, 7)])
 def test_gpu_sppf_pool_kernel_matches_torch(native, B, C, H, W, half):
-    """bf_sppf_pool(_f32)_device against nn.MaxPool2d(5, 1, 2) applied once, twice, three times: exact; the first quarter untouched."""
+    """bf_sppf_pool(_f32)_device against nn.MaxPool2d(5, 1, 2) applied once, twice, three times: exact; the first quarter untouched.
+    (The shapes walk the kernel's chunks-per-workgroup choice: 4, 2 and 1 by channel count, 1 by the LDS bound at 40 x 40.)"""
     import torch
     from lib import _native as nat
     g = torch.Generator(device="cpu").manual_seed(C + H)

@@ -793,37 +793,42 @@ __device__ __forceinline__ V maxv(V a, V b)
     return r;
 }
 template <typename T>
-__global__ void __launch_bounds__(256) sppf_pool_kernel(T* __restrict__ buf, int H, int W, int c)
+__global__ void __launch_bounds__(256) sppf_pool_kernel(T* __restrict__ buf, int H, int W, int c, int q)
 {
+    // A workgroup owns q adjacent 16-byte channel chunks of one image: an item is (pixel, chunk of the group), chunk fastest, so that q consecutive
+    // threads move 16 q contiguous bytes of a pixel (q = 4: a 64-byte run; one chunk per workgroup fetched a whole sector for every 16 bytes it used).
     typedef typename Elem<T>::vec vec;
     constexpr int E = Elem<T>::E;
-    extern __shared__ __attribute__((aligned(16))) unsigned char plane[];     // [2][H * W] chunks: current plane, row-pass result
+    extern __shared__ __attribute__((aligned(16))) unsigned char plane[];     // [2][H * W * q] chunks: current planes, row-pass result
+    const int groups = c / (E * q), b = blockIdx.x / groups, ch = (blockIdx.x % groups) * E * q, ld = 4 * c, P = H * W, items = P * q;
     vec* cur = reinterpret_cast<vec*>(plane);
-    vec* tmp = cur + H * W;
-    const int chunks = c / E, b = blockIdx.x / chunks, ch = (blockIdx.x % chunks) * E, ld = 4 * c, P = H * W;
+    vec* tmp = cur + items;
     T* img = buf + (size_t)b * P * ld + ch;
-    for (int p = threadIdx.x; p < P; p += 256) cur[p] = *reinterpret_cast<const vec*>(img + (size_t)p * ld);
+    for (int it = threadIdx.x; it < items; it += 256) {
+        const int p = it / q, j = it - p * q;
+        cur[it] = *reinterpret_cast<const vec*>(img + (size_t)p * ld + j * E);
+    }
     __syncthreads();
     for (int level = 1; level <= 3; ++level) {
-        for (int p = threadIdx.x; p < P; p += 256) {          // max over the row window
-            const int h = p / W, w = p - h * W;
-            vec m = cur[p];
+        for (int it = threadIdx.x; it < items; it += 256) {   // max over the row window
+            const int p = it / q, h = p / W, w = p - h * W;
+            vec m = cur[it];
             for (int d = 1; d <= 2; ++d) {
-                if (w - d >= 0) m = maxv(m, cur[p - d]);
-                if (w + d < W) m = maxv(m, cur[p + d]);
+                if (w - d >= 0) m = maxv(m, cur[it - d * q]);
+                if (w + d < W) m = maxv(m, cur[it + d * q]);
             }
-            tmp[p] = m;
+            tmp[it] = m;
         }
         __syncthreads();
-        for (int p = threadIdx.x; p < P; p += 256) {          // max over the column window, into the plane and the level's channel slice
-            const int h = p / W;
-            vec m = tmp[p];
+        for (int it = threadIdx.x; it < items; it += 256) {   // max over the column window, into the planes and the level's channel slice
+            const int p = it / q, j = it - p * q, h = p / W;
+            vec m = tmp[it];
             for (int d = 1; d <= 2; ++d) {
-                if (h - d >= 0) m = maxv(m, tmp[p - d * W]);
-                if (h + d < H) m = maxv(m, tmp[p + d * W]);
+                if (h - d >= 0) m = maxv(m, tmp[it - d * W * q]);
+                if (h + d < H) m = maxv(m, tmp[it + d * W * q]);
             }
-            cur[p] = m;       // (each thread rewrites only its own pixels of `cur`, which this pass does not read)
-            *reinterpret_cast<vec*>(img + (size_t)p * ld + level * c) = m;
+            cur[it] = m;      // (each thread rewrites only its own items of `cur`, which this pass does not read)
+            *reinterpret_cast<vec*>(img + (size_t)p * ld + level * c + j * E) = m;
         }
         __syncthreads();
     }
@@ -964,12 +969,16 @@ hipError_t launch_sppf_pool(void* buf, int B, int H, int W, int c, int elem_byte
 {
     const int E = 16 / elem_bytes;
     if (B <= 0 || H <= 0 || W <= 0 || c < E || (c % E) != 0 || (long long)H * W > 2048) return hipErrorInvalidValue;
-    const size_t lds = (size_t)2 * H * W * 16;
+    const int chunks = c / E;
+    int q = 4;                                                // chunks per workgroup: as many as divide the channel count and fit 64 KiB of LDS
+    while (q > 1 && ((chunks % q) != 0 || (size_t)2 * H * W * q * 16 > 64 * 1024)) q >>= 1;
+    const size_t lds = (size_t)2 * H * W * q * 16;
     const void* fn = elem_bytes == 4 ? reinterpret_cast<const void*>(sppf_pool_kernel<float>) : reinterpret_cast<const void*>(sppf_pool_kernel<_Float16>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    if (elem_bytes == 4) hipLaunchKernelGGL(sppf_pool_kernel<float>, dim3((unsigned)(B * (c / E))), dim3(256), lds, stream, static_cast<float*>(buf), H, W, c);
-    else hipLaunchKernelGGL(sppf_pool_kernel<_Float16>, dim3((unsigned)(B * (c / E))), dim3(256), lds, stream, static_cast<_Float16*>(buf), H, W, c);
+    const dim3 grid((unsigned)(B * (chunks / q)));
+    if (elem_bytes == 4) hipLaunchKernelGGL(sppf_pool_kernel<float>, grid, dim3(256), lds, stream, static_cast<float*>(buf), H, W, c, q);
+    else hipLaunchKernelGGL(sppf_pool_kernel<_Float16>, grid, dim3(256), lds, stream, static_cast<_Float16*>(buf), H, W, c, q);
     return hipGetLastError();
 }
 
